@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REAL reference (build container only).
+
+Run:  python tests/golden/make_golden.py          (writes tests/golden/*.npz)
+
+The reference (``/root/reference``, read-only, Python) cannot travel to the GPU
+box, so its outputs are captured here as small fixtures.  A fixture holds only
+*data*: seeds, inputs and the reference's outputs - never reference source.
+Weights come from the build's own deterministic generator
+(``oracle.cfnerf_oracle.make_params``) and are loaded into the reference module
+with ``load_state_dict``, so fixtures hold seeds instead of weights.
+
+Third-party modules the hot path never touches are stubbed:
+cv2, imageio, skimage.metrics, torch.utils.tensorboard, kornia, configargparse.
+Randomness is made explicit by temporarily replacing the two generator calls
+the hot path makes (``torch.rand`` RUN:524, ``Tensor.normal_`` MOD:234,246)
+with functions that hand back pre-chosen tensors; the reference's arithmetic is
+untouched.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from oracle import cfnerf_oracle as O  # noqa: E402
+
+
+def _stub_modules():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    mod("cv2")
+    mod("imageio")
+    sk = mod("skimage")
+    sk.metrics = mod("skimage.metrics", structural_similarity=lambda *a, **k: 0.0)
+    mod("kornia", create_meshgrid=lambda *a, **k: None)
+    mod("configargparse")
+    tb = mod("torch.utils.tensorboard", SummaryWriter=object)
+    torch.utils.tensorboard = tb
+
+
+def import_reference():
+    _stub_modules()
+    import run_nerf_uncertainty_NF as R   # noqa
+    torch.autograd.set_detect_anomaly(False)   # MOD:5 / HLP:2 turn it on at import
+    return R
+
+
+def ref_args(cfg: O.OracleCfg, tmpdir: str, **over):
+    a = argparse.Namespace(
+        multires=cfg.multires, multires_views=cfg.multires_views, i_embed=0, use_viewdirs=True,
+        N_importance=0, netdepth=cfg.netdepth, netwidth=cfg.netwidth, K_samples=cfg.K_samples,
+        h_alpha_size=cfg.h_alpha_size, h_rgb_size=cfg.h_rgb_size, z_size=4, n_flows=cfg.n_flows,
+        type_flows="triangular", n_hidden=128, netchunk_per_gpu=1024 * 64, n_gpus=1, lrate=5e-4,
+        ft_path=None, basedir=tmpdir, dataname="d", expname="e", no_reload=True, index_step=-1,
+        is_train=True, uniformsample=False, perturb=1.0, N_samples=128, white_bkgd=False,
+        raw_noise_std=0.0, dataset_type="llff", no_ndc=False, lindisp=False)
+    for k, v in over.items():
+        setattr(a, k, v)
+    os.makedirs(os.path.join(tmpdir, "d", "triangular", "e"), exist_ok=True)
+    return a
+
+
+class ExplicitRandom:
+    """Feed chosen tensors to the reference's torch.rand / Tensor.normal_ call sites."""
+
+    def __init__(self, t_rand=None, normals=()):
+        self.t_rand = t_rand
+        self.normals = list(normals)
+        self._orig_rand = torch.rand
+        self._orig_normal = torch.Tensor.normal_
+
+    def __enter__(self):
+        outer = self
+
+        def rand(*shape, **kw):
+            shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            assert outer.t_rand is not None and tuple(outer.t_rand.shape) == shp, (shp,)
+            return outer.t_rand.clone()
+
+        def normal_(self_t, *a, **k):
+            v = outer.normals.pop(0)
+            assert tuple(v.shape) == tuple(self_t.shape), (v.shape, self_t.shape)
+            self_t.copy_(v)
+            return self_t
+        torch.rand = rand
+        torch.Tensor.normal_ = normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig_rand
+        torch.Tensor.normal_ = self._orig_normal
+
+
+def build_reference_model(R, cfg, seed, tmpdir, **over):
+    args = ref_args(cfg, tmpdir, **over)
+    kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+    model = kw_train["network_fn"]                       # nn.DataParallel(NeRF_Flows)
+    p = O.make_params(cfg, seed)
+    sd = model.state_dict()
+    for k, v in p.items():
+        assert ("module." + k) in sd, k
+        sd["module." + k] = v.clone()
+    model.load_state_dict(sd)
+    return args, kw_train, kw_test, model, p, optimizer
+
+
+def fern_rays(rng, n, H=378, W=504, focal=407.5658):
+    """Fern-shaped synthetic rays: identity-ish pose, random pixels."""
+    c2w = np.eye(4, dtype=np.float32)[:3]
+    c2w[:, 3] = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    pix = rng.choice(H * W, size=n, replace=False)
+    j, i = np.divmod(pix, W)
+    dirs = np.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i, dtype=np.float64)], -1)
+    rays_d = (dirs[:, None, :] * c2w[:3, :3]).sum(-1).astype(np.float32)
+    rays_o = np.broadcast_to(c2w[:3, 3], rays_d.shape).astype(np.float32)
+    return np.stack([rays_o, rays_d], 0), (H, W, focal)
+
+
+def t2n(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        elif v is None:
+            continue
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def main():
+    R = import_reference()
+    import run_nerf_helpers as HLP
+    tmp = tempfile.mkdtemp(prefix="cfnerf_golden_")
+    rng = np.random.default_rng(1234)
+    out = {}
+
+    # ---------------- G8: encoder (HLP:54-69) ----------------
+    x = torch.tensor(rng.uniform(-1.5, 1.5, (16, 3)), dtype=torch.float32)
+    f10, d10 = HLP.get_embedder(10, 0)
+    f4, d4 = HLP.get_embedder(4, 0)
+    out["g8_encoder"] = dict(x=x, e10=f10(x), e4=f4(x), d10=d10, d4=d4)
+
+    # ---------------- G1/G2/G3: model (small width and full width) ----------------
+    for tag, cfg, seed, P in (("w64", O.OracleCfg(netwidth=64, K_samples=4), 11, 48),
+                              ("w256", O.OracleCfg(netwidth=256, K_samples=4), 12, 24),
+                              ("w64k1", O.OracleCfg(netwidth=64, K_samples=1), 13, 8),
+                              ("w128k5", O.OracleCfg(netwidth=128, K_samples=5, h_alpha_size=64, h_rgb_size=64), 14, 16)):
+        K = cfg.K_samples
+        args, kw_train, kw_test, model, p, _ = build_reference_model(R, cfg, seed, tmp, K_samples=K)
+        net = model.module
+        x90 = torch.tensor(rng.uniform(-1, 1, (P, 90)), dtype=torch.float32)
+        ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+        er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+        # G1 eval branch (MOD:192-223): module buffers, last sample zeroed by the reference itself
+        net.sample_alpha = ea.clone()
+        net.sample_rgb = er.clone()
+        with torch.no_grad():
+            raw_eval, aux = net(x90, False, True)
+            h_alpha, h_rgb = net.encode(x90)
+        # G2 train branch (MOD:225-291) with explicit epsilons
+        with ExplicitRandom(normals=[ea, er]):
+            raw_train, ent = net(x90, False, False)
+        # G3 flow units (MOD:387-416) on 5 rows, direct call with chosen z0/h
+        z0a = torch.tensor(rng.standard_normal((5, 1)), dtype=torch.float32)
+        ha = torch.tensor(rng.standard_normal((5, cfg.h_alpha_size)), dtype=torch.float32)
+        z0r = torch.tensor(rng.standard_normal((5, 3)), dtype=torch.float32)
+        hr = torch.tensor(rng.standard_normal((5, cfg.h_rgb_size)), dtype=torch.float32)
+        with torch.no_grad():
+            za_t, lda_t = net.flows_alpha(z0a, ha, False)
+            zr_t, ldr_t = net.flows_rgb(z0r, hr, False)
+            za_e, _ = net.flows_alpha(z0a, ha, True)
+            zr_e, _ = net.flows_rgb(z0r, hr, True)
+            r1, r2, b = net.flows_rgb.encode(hr)
+        out[f"g123_model_{tag}"] = dict(
+            seed=seed, netwidth=cfg.netwidth, K=K, h_alpha_size=cfg.h_alpha_size, h_rgb_size=cfg.h_rgb_size,
+            x90=x90, eps_alpha=ea, eps_rgb=er,
+            raw_eval=raw_eval, aux_eval_absmax=aux.abs().max(), h_alpha=h_alpha, h_rgb=h_rgb,
+            raw_train=raw_train, loss_entropy=ent.reshape(-1)[0], loss_entropy_shape=np.array(ent.shape),
+            z0a=z0a, ha=ha, z0r=z0r, hr=hr, za_train=za_t, lda_train=lda_t, zr_train=zr_t, ldr_train=ldr_t,
+            za_eval=za_e, zr_eval=zr_e, r1=r1, r2=r2, b=b)
+
+    # ---------------- G4: composite (RUN:411-454) ----------------
+    N, S, K = 8, 128, 4
+    raw = torch.tensor(rng.standard_normal((N, S, K, 4)) * 2.0, dtype=torch.float32)
+    raw[0, :, :, 3] = 30.0       # all-opaque ray
+    raw[1, :, :, 3] = -40.0      # all-empty ray
+    raw[2, :, 1, 3] = 25.0       # softplus linear branch (threshold 20) on one k
+    near = torch.tensor(rng.uniform(0.0, 0.5, (N, 1)), dtype=torch.float32)
+    far = near + torch.tensor(rng.uniform(0.5, 4.0, (N, 1)), dtype=torch.float32)
+    tv = O.t_vals_table()
+    z = near * (1 - tv) + far * tv
+    d = torch.tensor(rng.standard_normal((N, 3)), dtype=torch.float32)
+    g4 = dict(raw=raw, z_vals=z, rays_d=d)
+    for wb in (False, True):
+        with torch.no_grad():
+            rgb_map, disp, w, depth = R.raw2outputs(raw, z, d, 0, wb)
+        s = "wb" if wb else "nb"
+        g4.update({f"rgb_map_{s}": rgb_map, f"disp_{s}": disp, f"weights_{s}": w, f"depth_{s}": depth})
+    out["g4_composite"] = g4
+
+    # ---------------- G5: render on a ray batch, G7: train step ----------------
+    for tag, cfg, seed, n, over in (
+            ("w64_ndc", O.OracleCfg(netwidth=64, K_samples=4), 21, 32, dict()),
+            ("w64_nondc_lindisp_wb", O.OracleCfg(netwidth=64, K_samples=3), 22, 16,
+             dict(no_ndc=True, lindisp=True, white_bkgd=True)),
+            ("w256_ndc", O.OracleCfg(netwidth=256, K_samples=4), 23, 8, dict())):
+        K = cfg.K_samples
+        args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, seed, tmp, K_samples=K, **over)
+        net = model.module
+        rays, (H, W, focal) = fern_rays(rng, n)
+        rays_t = torch.tensor(rays)
+        near, far = (0., 1.) if not over.get("no_ndc") else (1.2, 8.0)
+        t_rand = torch.tensor(rng.uniform(0, 1, (n, 128)), dtype=torch.float32)
+        ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+        er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+        target = torch.tensor(rng.uniform(0, 1, (n, 3)), dtype=torch.float32)
+        # train-mode render (perturb=1) with explicit randomness
+        with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+            rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=near, far=far,
+                                                 verbose=False, retraw=False, **kw_train)
+        # G7: loss lines RUN:1027-1050 executed verbatim on the reference tensors
+        beta1 = 0.01
+        rgb_mean = torch.mean(rgbs, -1)
+        mse = HLP.img2mse(rgb_mean, target)
+        psnr = HLP.mse2psnr(mse)
+        import math
+        eps = 1e-05
+        nk = K
+        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+        H_sqrt = rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps
+        H_sqrt = H_sqrt[..., None]
+        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+        r_P_C_mean = (r_P_C_1 * r_P_C_2).mean(-1) + eps
+        loss_nll = -torch.log(r_P_C_mean).mean()
+        loss_entropy = extras["loss_entropy"].mean()
+        loss = loss_nll + beta1 * loss_entropy
+        optimizer.zero_grad()
+        loss.backward()
+        grads = {k[len("module."):]: (v.grad.clone() if v.grad is not None else None)
+                 for k, v in model.named_parameters()}
+        optimizer.step()
+        new_params = {k[len("module."):]: v.detach().clone() for k, v in model.named_parameters()}
+        # restore weights for the eval render (Adam moved them)
+        sd = model.state_dict()
+        for k, v in p.items():
+            sd["module." + k] = v.clone()
+        model.load_state_dict(sd)
+        # eval-mode render (perturb=0, fixed eps, last = 0)
+        net.sample_alpha = ea.clone()
+        net.sample_rgb = er.clone()
+        with torch.no_grad():
+            rgbs_e, disp_e, depth_e, extras_e = R.render(H, W, focal, chunk=8192, rays=rays_t, near=near, far=far,
+                                                         **kw_test)
+        g = dict(seed=seed, netwidth=cfg.netwidth, K=K, H=H, W=W, focal=focal, near=near, far=far,
+                 ndc=int(not over.get("no_ndc", False)), lindisp=int(over.get("lindisp", False)),
+                 white_bkgd=int(over.get("white_bkgd", False)), beta1=beta1,
+                 rays=rays_t, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, target=target,
+                 rgb_map=rgbs, disp_map=disp, depth_map=depth, raw=extras["raw"], pts=extras["pts"],
+                 loss_entropy=loss_entropy, loss_entropy_numel=extras["loss_entropy"].numel(),
+                 loss_nll=loss_nll, loss=loss, mse=mse, psnr=psnr.reshape(-1)[0],
+                 rgb_map_eval=rgbs_e, disp_map_eval=disp_e, depth_map_eval=depth_e,
+                 eval_extras_keys=np.array(sorted(extras_e.keys())), train_extras_keys=np.array(sorted(extras.keys())))
+        dead = []
+        for k, v in grads.items():
+            if v is None:
+                dead.append(k)
+            elif cfg.netwidth >= 256 and v.numel() > 4096:
+                # keep the full-width fixture small: first two rows + Frobenius norm of the big tensors
+                g["gradrows." + k] = v[:2]
+                g["gradnorm." + k] = v.double().norm()
+            else:
+                g["grad." + k] = v
+                g["adam1." + k] = new_params[k]
+        g["dead_params"] = np.array(sorted(dead))
+        out[f"g57_render_{tag}"] = g
+
+    # ---------------- G6: full tiny image via c2w (RUN:129-131, HLP:288-297) ----------------
+    cfg = O.OracleCfg(netwidth=64, K_samples=4)
+    args, kw_train, kw_test, model, p, _ = build_reference_model(R, cfg, 31, tmp, K_samples=4)
+    net = model.module
+    ea = torch.tensor(rng.standard_normal((4, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((4, 3)), dtype=torch.float32)
+    net.sample_alpha = ea.clone()
+    net.sample_rgb = er.clone()
+    th = 0.3
+    c2w = torch.tensor([[np.cos(th), 0, np.sin(th), 0.1], [0, 1, 0, -0.2], [-np.sin(th), 0, np.cos(th), 0.05]],
+                       dtype=torch.float32)
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, _ = R.render(6, 8, 7.0, chunk=8192, c2w=c2w, near=0., far=1., **kw_test)
+        ro, rd = HLP.get_rays(6, 8, 7.0, c2w)
+        no, nd = HLP.ndc_rays(6, 8, 7.0, 1., ro, rd)
+    out["g6_render_c2w"] = dict(seed=31, netwidth=64, K=4, H=6, W=8, focal=7.0, c2w=c2w, eps_alpha=ea, eps_rgb=er,
+                                rgb_map=rgbs_e, disp_map=disp_e, depth_map=depth_e, rays_o=ro, rays_d=rd,
+                                ndc_o=no, ndc_d=nd)
+
+    for name, d in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **t2n(d))
+        print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

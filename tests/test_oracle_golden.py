@@ -1,0 +1,195 @@
+"""Pin the CPU oracle (oracle/cfnerf_oracle.py) against golden vectors captured from the real
+reference (tests/golden/make_golden.py).  fp32 oracle vs fp32 reference: the two run the same
+ATen ops in (nearly) the same order, so the tolerance here is far tighter than the HIP one."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfnerf_oracle as O
+
+T = lambda a: torch.tensor(np.asarray(a))
+
+
+def close(a, b, atol=2e-6, rtol=2e-5, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert np.all(err <= tol), f"{what}: max err {err.max():.3e} (tol {tol.flat[err.argmax()]:.3e})"
+
+
+def cfg_from(g):
+    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]),
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
+
+
+def test_encoder(golden):
+    g = golden("g8_encoder")
+    assert int(g["d10"]) == 63 and int(g["d4"]) == 27
+    close(O.embed(T(g["x"]), 10), g["e10"], atol=0, rtol=0, what="embed10")   # bit-exact: same torch ops
+    close(O.embed(T(g["x"]), 4), g["e4"], atol=0, rtol=0, what="embed4")
+
+
+@pytest.mark.parametrize("tag", ["w64", "w256", "w64k1", "w128k5"])
+def test_model_forward(golden, tag):
+    g = golden(f"g123_model_{tag}")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    x = T(g["x90"])
+    ea, er = T(g["eps_alpha"]), T(g["eps_rgb"])
+    h_alpha, h_rgb = O.mlp_encode(p, x, cfg)
+    close(h_alpha, g["h_alpha"], what="h_alpha")
+    close(h_rgb, g["h_rgb"], what="h_rgb")
+    # eval: the reference zeroes the last latent sample itself (MOD:199,205)
+    ea0, er0 = ea.clone(), er.clone()
+    ea0[-1] = 0
+    er0[-1] = 0
+    raw_e, ent_e = O.nerf_flows_forward(p, x, ea0, er0, cfg, is_test=True)
+    assert ent_e is None and float(g["aux_eval_absmax"]) == 0.0
+    close(raw_e, g["raw_eval"], what="raw_eval")
+    raw_t, ent = O.nerf_flows_forward(p, x, ea, er, cfg, is_test=False)
+    close(raw_t, g["raw_train"], what="raw_train")
+    close(ent, g["loss_entropy"], atol=2e-6, rtol=1e-5, what="loss_entropy")
+    assert list(g["loss_entropy_shape"]) == [x.shape[0], cfg.K_samples, 1]
+
+
+@pytest.mark.parametrize("tag", ["w64", "w256", "w128k5"])
+def test_flow_units(golden, tag):
+    g = golden(f"g123_model_{tag}")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    za, lda = O.sylvester_flow(p, "flows_alpha", T(g["z0a"]), T(g["ha"]), cfg.n_flows, False)
+    zr, ldr = O.sylvester_flow(p, "flows_rgb", T(g["z0r"]), T(g["hr"]), cfg.n_flows, False)
+    close(za, g["za_train"], what="za")
+    close(lda, g["lda_train"], what="lda")
+    close(zr, g["zr_train"], what="zr")
+    close(ldr, g["ldr_train"], what="ldr")
+    close(O.sylvester_flow(p, "flows_alpha", T(g["z0a"]), T(g["ha"]), cfg.n_flows, True)[0], g["za_eval"])
+    close(O.sylvester_flow(p, "flows_rgb", T(g["z0r"]), T(g["hr"]), cfg.n_flows, True)[0], g["zr_eval"])
+    r1, r2, b = O.flow_encode(p, "flows_rgb", T(g["hr"]), 3, cfg.n_flows)
+    close(r1, g["r1"], what="r1")
+    close(r2, g["r2"], what="r2")
+    close(b, g["b"], what="b")
+
+
+@pytest.mark.parametrize("wb", [False, True])
+def test_composite(golden, wb):
+    g = golden("g4_composite")
+    s = "wb" if wb else "nb"
+    rgb_map, disp, w, depth = O.raw2outputs(T(g["raw"]), T(g["z_vals"]), T(g["rays_d"]), wb)
+    close(rgb_map, g[f"rgb_map_{s}"], atol=0, rtol=0, what="rgb_map")
+    close(disp, g[f"disp_{s}"], atol=0, rtol=0, what="disp")
+    close(w, g[f"weights_{s}"], atol=0, rtol=0, what="weights")
+    close(depth, g[f"depth_{s}"], atol=0, rtol=0, what="depth")
+    # edge rays: the opaque ray's weights sum to 1; the empty ray accumulates ~nothing
+    assert np.allclose(g[f"weights_{s}"][0].sum(0), 1.0, atol=1e-5)
+    assert np.abs(g[f"weights_{s}"][1]).max() < 1e-12
+
+
+def _render_inputs(g):
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    kw = dict(ndc=bool(g["ndc"]), near=float(g["near"]), far=float(g["far"]), lindisp=bool(g["lindisp"]),
+              white_bkgd=bool(g["white_bkgd"]))
+    return cfg, p, rays, kw
+
+
+@pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
+def test_render_batch(golden, tag):
+    g = golden(f"g57_render_{tag}")
+    cfg, p, rays, kw = _render_inputs(g)
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    ea, er = T(g["eps_alpha"]), T(g["eps_rgb"])
+    r = O.render(p, H, W, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=T(g["t_rand"]), **kw)
+    close(r["pts"], g["pts"], atol=1e-6, what="pts")
+    close(r["raw"], g["raw"], atol=5e-6, rtol=5e-5, what="raw")
+    close(r["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(r["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5, what="depth_map")
+    close(r["disp_map"], g["disp_map"], atol=5e-5, rtol=5e-5, what="disp_map")
+    close(r["loss_entropy"], g["loss_entropy"], atol=5e-6, rtol=1e-5, what="entropy")
+    assert list(g["train_extras_keys"]) == ["loss_entropy", "pts", "raw"]
+    assert list(g["eval_extras_keys"]) == []
+    ea0, er0 = ea.clone(), er.clone()
+    ea0[-1] = 0
+    er0[-1] = 0
+    e = O.render(p, H, W, focal, cfg, ea0, er0, False, rays=(rays[0], rays[1]), t_rand=None, **kw)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")
+    close(e["depth_map"], g["depth_map_eval"], atol=5e-6, rtol=5e-5, what="depth_eval")
+    close(e["disp_map"], g["disp_map_eval"], atol=5e-5, rtol=5e-5, what="disp_eval")
+
+
+@pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
+def test_train_step(golden, tag):
+    g = golden(f"g57_render_{tag}")
+    cfg, p, rays, kw = _render_inputs(g)
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    packed = O.pack_rays(H, W, focal, rays[0], rays[1], kw["ndc"], kw["near"], kw["far"])
+    scal, grads, ret = O.train_step(p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]),
+                                    T(g["t_rand"]), float(g["beta1"]), kw["lindisp"], kw["white_bkgd"])
+    close(scal["loss_nll"], g["loss_nll"], rtol=2e-5, what="nll")
+    close(scal["loss"], g["loss"], rtol=2e-5, what="loss")
+    close(scal["mse"], g["mse"], rtol=2e-5, what="mse")
+    close(scal["psnr"], g["psnr"], rtol=2e-5, what="psnr")
+    dead = set(g["dead_params"].tolist())
+    # R13: the reference leaves exactly these without a gradient
+    assert dead == {"alpha_linear.weight", "alpha_linear.bias", "alpha_std_linear.weight", "alpha_std_linear.bias"}
+    n_checked = 0
+    for k in p:
+        if ("grad." + k) in g:
+            ref = g["grad." + k]
+            scale = max(1e-7, float(np.abs(ref).max()))
+            close(grads[k], ref, atol=2e-4 * scale, rtol=1e-3, what="grad " + k)
+            n_checked += 1
+        elif ("gradrows." + k) in g:
+            ref = g["gradrows." + k]
+            scale = max(1e-7, float(np.abs(ref).max()))
+            close(grads[k][:2], ref, atol=2e-4 * scale, rtol=1e-3, what="gradrows " + k)
+            close(grads[k].double().norm(), g["gradnorm." + k], rtol=1e-4, what="gradnorm " + k)
+            n_checked += 1
+        else:
+            assert k in dead, k
+            assert grads[k] is None
+    assert n_checked >= 30
+    # flows_alpha.amor_d is fully masked for z = 1 (R13): zero gradient, not None
+    assert float(np.abs(g["grad.flows_alpha.amor_d.weight"]).max()) == 0.0
+    # one Adam step (RUN:339,1067)
+    state = {}
+    newp = O.adam_step({k: v.clone() for k, v in p.items()}, grads, state, step=1, lr=5e-4)
+    for k in p:
+        if ("adam1." + k) in g:
+            close(newp[k], g["adam1." + k], atol=2e-6, rtol=1e-5, what="adam " + k)
+
+
+def test_render_c2w(golden):
+    g = golden("g6_render_c2w")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    ro, rd = O.get_rays(H, W, focal, T(g["c2w"]))
+    close(ro, g["rays_o"], atol=0, rtol=0)
+    close(rd, g["rays_d"], atol=1e-7)
+    no, nd = O.ndc_rays(H, W, focal, 1.0, ro, rd)
+    close(no, g["ndc_o"], atol=1e-6)
+    close(nd, g["ndc_d"], atol=1e-6)
+    ea, er = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    ea[-1] = 0
+    er[-1] = 0
+    e = O.render(p, H, W, focal, cfg, ea, er, False, c2w=T(g["c2w"]), near=0., far=1.)
+    assert list(e["rgb_map"].shape) == [H, W, 3, 4]
+    close(e["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5)
+    close(e["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5)
+    close(e["disp_map"], g["disp_map"], atol=5e-5, rtol=5e-5)
+
+
+def test_oracle_fp64_vs_fp32_drift(golden):
+    """The reference's own fp32-vs-fp64 drift bounds what 'fp32 tolerance' can mean."""
+    g = golden("g57_render_w64_ndc")
+    cfg, p, rays, kw = _render_inputs(g)
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    p64 = {k: v.double() for k, v in p.items()}
+    r = O.render(p64, H, W, focal, cfg, T(g["eps_alpha"]).double(), T(g["eps_rgb"]).double(), True,
+                 rays=(rays[0].double(), rays[1].double()), t_rand=T(g["t_rand"]).double(), **kw)
+    close(r["rgb_map"], g["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map fp64 vs ref fp32")
+    close(r["depth_map"], g["depth_map"], atol=1e-5, rtol=1e-4, what="depth fp64 vs ref fp32")
