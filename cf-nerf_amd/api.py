@@ -1,0 +1,658 @@
+"""Host-side mirror of the reference's hot-path interface, backed by libcfnerf_hip.so.
+
+Same names, argument order, defaults and return structure as the reference
+(RUN = run_nerf_uncertainty_NF.py, HLP = run_nerf_helpers.py, MOD = model/models.py):
+
+    render            RUN:103-170      render_rays     RUN:457-553
+    run_network       RUN:67-85        raw2outputs     RUN:411-454
+    batchify(_rays)   RUN:47-64,88-100 create_nerf     RUN:317-409
+    NeRF_Flows        MOD:13-291       get_embedder    HLP:54-69
+    get_rays/ndc_rays HLP:288-297,360-377   img2mse/mse2psnr HLP:15-16
+
+All arithmetic of the path runs in hand-written HIP kernels; PyTorch only owns device memory,
+streams, autograd plumbing and the optimiser.  There is no CPU / eager fallback: every function
+raises if the library is missing or the tensors are not on a GPU.
+
+Extra (new) keyword arguments make the reference's hidden randomness explicit:
+``t_rand [N,S]``, ``eps_alpha [K,1]``, ``eps_rgb [K,3]``.  When left ``None`` they are drawn with
+torch in the reference's order (RUN:524 -> MOD:234 -> MOD:246).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------------------------
+# misc helpers (HLP:15-16)
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU: the CF-NeRF hot path is HIP-only (no CPU fallback)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# positional encoding (HLP:21-69).  Used only by the unfused run_network path and by callers that
+# want the embedding itself; the fused kernels encode on-chip.
+class Embedder:
+    def __init__(self, multires: int, input_dims: int = 3):
+        self.multires = multires
+        self.input_dims = input_dims
+        self.out_dim = input_dims * (1 + 2 * multires)
+        self.freq_bands = 2. ** torch.linspace(0., multires - 1, steps=multires)     # HLP:38
+
+    def embed(self, inputs: torch.Tensor) -> torch.Tensor:
+        out = [inputs]
+        for f in self.freq_bands.tolist():                                            # HLP:42-45
+            out.append(torch.sin(inputs * f))
+            out.append(torch.cos(inputs * f))
+        return torch.cat(out, -1)                                                     # HLP:51
+
+
+def get_embedder(multires, i=0):
+    if i == -1:
+        return nn.Identity(), 3                                                       # HLP:55-56
+    eo = Embedder(multires)
+    fn = lambda x, eo=eo: eo.embed(x)
+    fn.multires = multires
+    return fn, eo.out_dim
+
+
+# --------------------------------------------------------------------------------------------
+# ray helpers (HLP:288-297, 360-377): torch versions for API parity; render() itself uses the
+# cfnerf_rays_setup kernel.
+def get_rays(H, W, focal, c2w):
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=c2w.device),
+                          torch.linspace(0, H - 1, H, device=c2w.device), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    sx, sy = -1. / (W / (2. * focal)), -1. / (H / (2. * focal))
+    o = torch.stack([sx * rays_o[..., 0] / rays_o[..., 2], sy * rays_o[..., 1] / rays_o[..., 2],
+                     1. + 2. * near / rays_o[..., 2]], -1)
+    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2]),
+                     sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2]),
+                     -2. * near / rays_o[..., 2]], -1)
+    return o, d
+
+
+def t_vals_table(device=None) -> torch.Tensor:
+    """The hard-coded 96 + 32 = 128 sample table of RUN:510 (computed on the CPU like the reference)."""
+    t = torch.cat([torch.linspace(0., 0.5, steps=97)[:-1], torch.linspace(0.5, 1., steps=32)], 0)
+    return t.to(device) if device is not None else t
+
+
+# --------------------------------------------------------------------------------------------
+# parameter layout (mirror of cfnerf_param_key / cfnerf_param_offset)
+def _cfg_struct(netdepth, netwidth, multires, multires_views, h_alpha_size, h_rgb_size, n_flows) -> L.Cfg:
+    return L.Cfg(int(netdepth), int(netwidth), int(multires), int(multires_views), int(h_alpha_size),
+                 int(h_rgb_size), int(n_flows))
+
+
+def param_layout(cfg: L.Cfg):
+    """OrderedDict key -> (offset, shape) in the flat parameter buffer, as the C ABI defines it."""
+    lib = L.lib()
+    total = lib.cfnerf_param_count(C.byref(cfg))
+    if total < 0:
+        raise RuntimeError("unsupported configuration: " + lib.cfnerf_last_error().decode())
+    out = OrderedDict()
+    i = 0
+    W, D = cfg.netwidth, cfg.netdepth
+    while True:
+        k = lib.cfnerf_param_key(C.byref(cfg), i)
+        if k is None:
+            break
+        key = k.decode()
+        n = C.c_int64(0)
+        off = lib.cfnerf_param_offset(C.byref(cfg), k, C.byref(n))
+        out[key] = (int(off), int(n.value))
+        i += 1
+    return out, int(total)
+
+
+def _shape_of(key: str, numel: int, cfg: L.Cfg):
+    if key.endswith(".weight"):
+        W, ic, icv = cfg.netwidth, 3 + 6 * cfg.multires, 3 + 6 * cfg.multires_views
+        rows = {"views_linears.0.weight": W // 2, "feature_linear.weight": W, "alpha_linear.weight": 1,
+                "alpha_std_linear.weight": 1, "h_alpha_linear.weight": cfg.h_alpha_size,
+                "h_rgb_linear.weight": cfg.h_rgb_size}.get(key)
+        if rows is None:
+            if key.startswith("pts_linears."):
+                rows = W
+            elif key.startswith("flows_rgb."):
+                rows = cfg.n_flows * (9 if ".amor_d." in key else 3)
+            else:
+                rows = cfg.n_flows
+        return (rows, numel // rows)
+    return (numel,)
+
+
+# --------------------------------------------------------------------------------------------
+class NeRF_Flows(nn.Module):
+    """Drop-in for the reference's ``NeRF_Flows`` (MOD:13-291).
+
+    All parameters live in ONE flat fp32 tensor ``self.flat`` (the layout of ``state_dict()``),
+    which is what the kernels, the gradient all-reduce and the fused Adam work on.
+    ``state_dict()`` / ``load_state_dict()`` speak the reference's key names (with the buffers
+    ``flip_idx`` / ``triu_mask`` / ``diag_idx``), so released checkpoints load unchanged.
+    """
+
+    def __init__(self, args):
+        super().__init__()
+        self.D = args.netdepth
+        self.W = args.netwidth
+        self.input_ch = args.input_ch
+        self.input_ch_views = args.input_ch_views
+        self.K_samples = args.K_samples
+        self.skips = args.skips
+        self.use_viewdirs = args.use_viewdirs
+        self.h_alpha_size = args.h_alpha_size
+        self.h_rgb_size = args.h_rgb_size
+        args.z_size = 3                                            # MOD:31
+        self.z_size = 3
+        self.n_flows = args.n_flows
+        self.type_flows = getattr(args, "type_flows", "triangular")
+        self.n_hidden = getattr(args, "n_hidden", 128)
+        dev = torch.device(getattr(args, "device", "cuda"))
+        if dev.type != "cuda":
+            raise RuntimeError("NeRF_Flows needs a GPU device: the CF-NeRF hot path is HIP-only")
+        self.device = dev
+        if not self.use_viewdirs:
+            # the reference crashes later with an AttributeError (MOD:63-64,183-186); reject up front
+            raise ValueError("use_viewdirs=False is not supported (the reference's NeRF_Flows cannot run it either)")
+        if list(self.skips) != [self.D / 2] and list(self.skips) != [self.D // 2]:
+            raise ValueError(f"skips must be [netdepth/2] (RUN:327), got {self.skips}")
+        if (self.input_ch - 3) % 6 or (self.input_ch_views - 3) % 6:
+            raise ValueError("input_ch / input_ch_views must come from get_embedder (3 + 6*multires)")
+        self.cfg = _cfg_struct(self.D, self.W, (self.input_ch - 3) // 6, (self.input_ch_views - 3) // 6,
+                               self.h_alpha_size, self.h_rgb_size, self.n_flows)
+        self.layout, n_params = param_layout(self.cfg)
+        self.n_params = n_params
+        self.flat = nn.Parameter(torch.zeros(n_params, dtype=torch.float32, device=dev))
+        self.reset_parameters()
+        # eval latents: plain attributes drawn at construction, NOT in state_dict (MOD:50-55)
+        self.sample_size = args.K_samples
+        self.sample_alpha = torch.empty([self.sample_size, 1]).normal_()
+        self.sample_rgb = torch.empty([self.sample_size, 3]).normal_()
+        h = C.c_void_p()
+        L.check(L.lib().cfnerf_model_create(C.byref(self.cfg), C.byref(h)), "cfnerf_model_create")
+        self._h = h
+        self._packed_version = None
+
+    # ---- parameters ------------------------------------------------------------------------
+    def view(self, key: str) -> torch.Tensor:
+        off, n = self.layout[key]
+        return self.flat.data[off:off + n].view(_shape_of(key, n, self.cfg))
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """nn.Linear default init (Kaiming-uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias);
+        base Gaussians mean 0 / std 1 (MOD:44-48)."""
+        for key in self.layout:
+            v = self.view(key)
+            if key in ("alpha_mean", "rgb_mean"):
+                v.zero_()
+            elif key in ("alpha_std", "rgb_std"):
+                v.fill_(1.0)
+            elif key.endswith(".weight"):
+                v.uniform_(-1.0 / math.sqrt(v.shape[1]), 1.0 / math.sqrt(v.shape[1]))
+            else:
+                w = self.view(key[:-len("bias")] + "weight")
+                v.uniform_(-1.0 / math.sqrt(w.shape[1]), 1.0 / math.sqrt(w.shape[1]))
+        self._dirty = True
+
+    def _buffers_ref(self):
+        out = OrderedDict()
+        for name, z in (("flows_rgb", 3), ("flows_alpha", 1)):
+            out[f"{name}.flip_idx"] = torch.arange(z - 1, -1, -1, device=self.device).long()       # MOD:323
+            out[f"{name}.triu_mask"] = torch.triu(torch.ones(z, z, device=self.device), diagonal=1)[None, :, :, None]
+            out[f"{name}.diag_idx"] = torch.arange(0, z, device=self.device).long()
+            for k in range(self.n_flows):
+                out[f"{name}.flow_{k}.diag_idx"] = torch.arange(0, z, device=self.device).long()   # FLW:180-181
+        return out
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for key in self.layout:
+            v = self.view(key)
+            destination[prefix + key] = v if keep_vars else v.detach().clone()
+        for k, v in self._buffers_ref().items():
+            destination[prefix + k] = v
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        bufs = self._buffers_ref()
+        with torch.no_grad():
+            for key in self.layout:
+                k = prefix + key
+                if k in state_dict:
+                    src = state_dict[k]
+                    dst = self.view(key)
+                    if tuple(src.shape) != tuple(dst.shape):
+                        error_msgs.append(f"size mismatch for {k}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                        continue
+                    dst.copy_(src.to(dst.device, torch.float32))
+                elif strict:
+                    missing_keys.append(k)
+        self._dirty = True                  # re-pack before the next launch
+        if strict:
+            for k in state_dict:
+                if k.startswith(prefix) and k[len(prefix):] not in self.layout and k[len(prefix):] not in bufs:
+                    unexpected_keys.append(k)
+
+    def _sync(self):
+        """Re-pack the MFMA-ordered weight copies if ``flat`` changed (optimizer.step, load_state_dict)."""
+        if (getattr(self, "_dirty", True) or self.flat.data_ptr() != getattr(self, "_packed_ptr", None)
+                or self.flat._version != self._packed_version):
+            L.check(L.lib().cfnerf_model_set_params(self._h, L.ptr(self.flat.data), L.stream()), "cfnerf_model_set_params")
+            self.mark_packed()
+
+    def mark_packed(self):
+        """Tell the module that the library already re-packed (cfnerf_adam_step does)."""
+        self._packed_version = self.flat._version
+        self._packed_ptr = self.flat.data_ptr()
+        self._dirty = False
+
+    def mark_dirty(self):
+        """Call after writing into ``flat.data`` / ``view(key)`` directly."""
+        self._dirty = True
+
+    @property
+    def handle(self):
+        return self._h
+
+    def eval_eps(self):
+        """[K,4] eval latents: the fixed buffers with the LAST sample zeroed (MOD:199,205)."""
+        e = torch.cat([self.sample_rgb, self.sample_alpha], -1).to(torch.float32).clone()
+        e[-1] = 0
+        return e.to(self.device)
+
+    def draw_eps(self):
+        """Fresh train latents in the reference's order: eps_alpha then eps_rgb (MOD:234,246)."""
+        ea = torch.empty([self.K_samples, 1]).normal_()
+        er = torch.empty([self.K_samples, 3]).normal_()
+        return torch.cat([er, ea], -1).to(self.device)
+
+    # ---- forward (MOD:188-291) ---------------------------------------------------------------
+    def forward(self, x, is_val=False, is_test=False, eps_alpha=None, eps_rgb=None):
+        _need_gpu(x, "x")
+        if x.shape[-1] != self.input_ch + self.input_ch_views:
+            raise ValueError(f"x must have {self.input_ch + self.input_ch_views} channels, got {x.shape[-1]}")
+        if torch.is_grad_enabled() and self.flat.requires_grad and not is_test:
+            raise RuntimeError("autograd through NeRF_Flows.forward is not available; train through render()/render_rays()")
+        self._sync()
+        xf = _f32c(x.reshape(-1, x.shape[-1]))
+        P, K = xf.shape[0], self.K_samples
+        if eps_alpha is not None or eps_rgb is not None:
+            eps = torch.cat([eps_rgb, eps_alpha], -1).to(self.device, torch.float32).contiguous()
+        else:
+            eps = self.eval_eps() if is_test else self.draw_eps()
+        raw = torch.empty(P, K, 4, device=self.device, dtype=torch.float32)
+        ent = torch.zeros(1, device=self.device, dtype=torch.float32)
+        flags = 0 if is_test else L.F_TRAIN
+        L.check(L.lib().cfnerf_network_fwd(self._h, L.ptr(xf), L.ptr(eps), P, K, flags, L.ptr(raw), L.ptr(ent), L.stream()),
+                "cfnerf_network_fwd")
+        if is_test:
+            return raw, torch.zeros_like(raw)                        # MOD:223
+        return raw, ent.reshape(1, 1, 1).expand(P, K, 1)             # MOD:291
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                L.lib().cfnerf_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class _DataParallelShim(nn.Module):
+    """Stands where the reference puts ``nn.DataParallel(model)`` (RUN:330): same ``.module`` attribute and
+    the same ``module.``-prefixed ``state_dict`` keys, but no replication - multi-GPU is one process per
+    GPU with ray sharding (see cf-nerf_amd/train.py)."""
+
+    def __init__(self, module: NeRF_Flows):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def _unwrap(network_fn) -> NeRF_Flows:
+    m = network_fn.module if isinstance(network_fn, _DataParallelShim) else network_fn
+    if not isinstance(m, NeRF_Flows):
+        raise TypeError("network_fn must be the NeRF_Flows returned by create_nerf")
+    return m
+
+
+# --------------------------------------------------------------------------------------------
+def batchify(fn, chunk):
+    """RUN:47-64.  The kernels tile internally, so chunking only bounds the size of one launch."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs, is_val, is_test):
+        A, B = [], []
+        for i in range(0, inputs.shape[0], chunk):
+            a, b = fn(inputs[i:i + chunk], is_val, is_test)
+            A.append(a)
+            B.append(b)
+        return torch.cat(A, 0), torch.cat(B, 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, is_val, is_test, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """RUN:67-85 (the unfused query: embed with torch, then the network kernel)."""
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape) if viewdirs.ndim == inputs.ndim - 1 else viewdirs
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
+    outputs_flat, loss_entropy = batchify(fn, netchunk)(embedded, is_val, is_test)
+    outputs = torch.reshape(outputs_flat, list(inputs.shape[:-1]) + list(outputs_flat.shape[-2:]))
+    return outputs, loss_entropy
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """RUN:411-454 on the standalone composite kernel.  ``raw_noise_std`` is accepted and has no effect,
+    exactly like the reference (the noise is generated but never added, RUN:432-442)."""
+    _need_gpu(raw, "raw")
+    N, S, K = raw.shape[0], raw.shape[1], raw.shape[2]
+    raw_c, z_c, d_c = _f32c(raw), _f32c(z_vals), _f32c(rays_d)
+    dev = raw.device
+    rgb_map = torch.empty(N, 3, K, device=dev)
+    disp_map = torch.empty(N, K, device=dev)
+    depth_map = torch.empty(N, K, device=dev)
+    weights = torch.empty(N, S, K, device=dev)
+    L.check(L.lib().cfnerf_composite_fwd(L.ptr(raw_c), L.ptr(z_c), L.ptr(d_c), N, S, K, int(bool(white_bkgd)),
+                                         L.ptr(rgb_map), L.ptr(disp_map), L.ptr(depth_map), L.ptr(weights), L.stream()),
+            "cfnerf_composite_fwd")
+    return rgb_map, disp_map, weights, depth_map
+
+
+# --------------------------------------------------------------------------------------------
+class _RenderFn(torch.autograd.Function):
+    """Fused render (forward with activation stash) + cfnerf_render_bwd."""
+
+    @staticmethod
+    def forward(ctx, flat, model, rays, t_vals, t_rand, eps, flags, want_pts):
+        N, S, K = rays.shape[0], t_vals.shape[0], eps.shape[0]
+        dev = rays.device
+        rgb_map = torch.empty(N, 3, K, device=dev)
+        disp = torch.empty(N, K, device=dev)
+        depth = torch.empty(N, K, device=dev)
+        raw = torch.empty(N, S, K, 4, device=dev)
+        pts = torch.empty(N, S, 3, device=dev) if want_pts else None
+        ent = torch.zeros(1, device=dev)
+        L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K,
+                                          flags | L.F_STASH, L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), None,
+                                          L.ptr(pts), L.ptr(ent), L.stream()), "cfnerf_render_fwd")
+        ctx.model = model
+        ctx.n_params = flat.numel()
+        ctx.mark_non_differentiable(disp, raw)
+        if pts is None:
+            pts = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(pts)
+        return rgb_map, disp, depth, ent.reshape(()), raw, pts
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_disp, d_depth, d_ent, d_raw, d_pts):
+        model = ctx.model
+        dev = model.flat.device
+        grad = torch.empty(ctx.n_params, device=dev)
+        d_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(model._last_shape, device=dev)
+        dd = _f32c(d_depth) if d_depth is not None else None
+        de = _f32c(d_ent.reshape(1)) if d_ent is not None else None
+        L.check(L.lib().cfnerf_render_bwd(model.handle, L.ptr(d_rgb), L.ptr(dd), L.ptr(de), L.ptr(grad), L.stream()),
+                "cfnerf_render_bwd")
+        return grad, None, None, None, None, None, None, None
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, uniformsample, retraw=False,
+                lindisp=False, K_samples=0, perturb=0., N_importance=0, network_fine=None, white_bkgd=False,
+                raw_noise_std=0., verbose=False, pytest=False, t_rand=None, eps_alpha=None, eps_rgb=None,
+                t_vals=None, retweights=False):
+    """Volumetric rendering of a ray batch (RUN:457-553) in ONE fused launch.
+
+    Returns ``{'rgb_map' [N,3,K], 'disp_map' [N,K], 'depth_map' [N,K]}`` plus ``raw``, ``loss_entropy``
+    and ``pts`` when ``is_train`` (RUN:542-547).  ``retraw``, ``uniformsample``, ``K_samples``, ``verbose``
+    are accepted and never read, like the reference; ``N_importance > 0`` / ``network_fine`` - which the
+    reference silently ignores (there is no fine pass) - are rejected.
+    """
+    _need_gpu(ray_batch, "ray_batch")
+    if N_importance and N_importance > 0 or network_fine is not None:
+        raise NotImplementedError("the reference has no hierarchical/fine pass (N_importance is dead there); refusing to ignore it")
+    if ray_batch.shape[-1] != 11:
+        raise ValueError("ray_batch must be [N,11] = o3,d3,near,far,viewdir3 (use_viewdirs=True)")
+    model = _unwrap(network_fn)
+    dev = ray_batch.device
+    if t_vals is None:
+        t_vals = t_vals_table(dev)
+        if N_samples != t_vals.shape[0]:
+            # the reference's z_vals.expand([N_rays, N_samples]) raises for any other value (RUN:510,516)
+            raise ValueError(f"N_samples must be {t_vals.shape[0]} (hard-coded sample table, RUN:510); pass t_vals= to override")
+    else:
+        t_vals = t_vals.to(dev, torch.float32).contiguous()
+    N, S, K = ray_batch.shape[0], t_vals.shape[0], model.K_samples
+    rays = _f32c(ray_batch)
+    # randomness, in the reference's order: t_rand (RUN:524), eps_alpha (MOD:234), eps_rgb (MOD:246)
+    if perturb > 0.:
+        if t_rand is None:
+            t_rand = torch.rand([N, S]).to(dev) if not pytest else torch.tensor(__import__("numpy").random.rand(N, S), dtype=torch.float32).to(dev)
+        t_rand = _f32c(t_rand.to(dev))
+    else:
+        t_rand = None
+    if eps_alpha is not None or eps_rgb is not None:
+        eps = torch.cat([eps_rgb, eps_alpha], -1).to(dev, torch.float32).contiguous()
+    else:
+        eps = model.draw_eps() if is_train else model.eval_eps()
+    flags = (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0) | (L.F_TRAIN if is_train else 0)
+    model._sync()
+
+    fused = network_query_fn is None or getattr(network_query_fn, "_cfnerf_fused", False)
+    if not fused:
+        return _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_rand, eps, is_train, lindisp, white_bkgd)
+
+    if is_train and torch.is_grad_enabled() and model.flat.requires_grad:
+        model._last_shape = (N, 3, K)
+        rgb_map, disp, depth, ent, raw, pts = _RenderFn.apply(model.flat, model, rays, t_vals, t_rand, eps, flags, True)
+        return {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth, 'raw': raw,
+                'loss_entropy': ent.reshape(1, 1, 1).expand(N * S, K, 1), 'pts': pts}
+
+    rgb_map = torch.empty(N, 3, K, device=dev)
+    disp = torch.empty(N, K, device=dev)
+    depth = torch.empty(N, K, device=dev)
+    raw = torch.empty(N, S, K, 4, device=dev) if is_train else None
+    pts = torch.empty(N, S, 3, device=dev) if is_train else None
+    wts = torch.empty(N, S, K, device=dev) if retweights else None
+    ent = torch.zeros(1, device=dev)
+    L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K, flags,
+                                      L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), L.ptr(wts), L.ptr(pts), L.ptr(ent),
+                                      L.stream()), "cfnerf_render_fwd")
+    ret = {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth}
+    if is_train:
+        ret['raw'] = raw
+        ret['loss_entropy'] = ent.reshape(1, 1, 1).expand(N * S, K, 1)
+        ret['pts'] = pts
+    if retweights:
+        ret['weights'] = wts
+    return ret
+
+
+def _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_rand, eps, is_train, lindisp, white_bkgd):
+    """A caller-supplied network_query_fn: sample with torch, query through it, composite kernel."""
+    rays_o, rays_d, viewdirs = rays[:, 0:3], rays[:, 3:6], rays[:, 8:11]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    if not lindisp:
+        z_vals = near * (1. - t_vals) + far * t_vals
+    else:
+        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    z_vals = z_vals.expand([rays.shape[0], t_vals.shape[0]])
+    if t_rand is not None:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * t_rand
+    pts0 = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    model._next_eps = eps
+    raw, loss_entropy = network_query_fn(pts0, viewdirs, network_fn, is_val=False, is_test=not is_train)
+    rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals.contiguous(), rays_d, 0., white_bkgd)
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'depth_map': depth_map}
+    if is_train:
+        ret.update(raw=raw, loss_entropy=loss_entropy, pts=pts0)
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """RUN:88-100."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (torch.cat(v, 0) if len(v) > 1 else v[0]) for k, v in all_ret.items()}
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """Render rays (RUN:103-170).  Returns ``[rgb_map [..,3,K], disp_map [..,K], depth_map [..,K], extras]``.
+
+    ``chunk`` does not affect results (RUN:112-113); here it does not even split the launch: the fused
+    kernel tiles rays internally and keeps nothing per-point in HBM, so one launch renders the batch.
+    """
+    if not use_viewdirs:
+        raise ValueError("use_viewdirs=False is not supported (the reference's model cannot run it, SURVEY R8)")
+    lib = L.lib()
+    if c2w is not None:
+        c2w_t = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
+        dev = kwargs["network_fn"].module.device if hasattr(kwargs.get("network_fn"), "module") else _unwrap(kwargs["network_fn"]).device
+        sh = (H, W, 3)
+        N = H * W
+        packed = torch.empty(N, 11, device=dev)
+        arr = (C.c_float * 12)(*c2w_t.reshape(-1).tolist())
+        if c2w_staticcam is None:
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, int(bool(ndc)), float(near), float(far),
+                                          L.ptr(packed), L.stream()), "cfnerf_rays_setup")
+        else:   # RUN:139-141: view directions from c2w, geometry from the static camera
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, float(near), float(far), L.ptr(packed),
+                                          L.stream()), "cfnerf_rays_setup")
+            vd = packed[:, 8:11].clone()
+            sc = torch.as_tensor(c2w_staticcam, dtype=torch.float32).cpu()[:3, :4].contiguous()
+            arr2 = (C.c_float * 12)(*sc.reshape(-1).tolist())
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr2, None, None, N, int(bool(ndc)), float(near), float(far),
+                                          L.ptr(packed), L.stream()), "cfnerf_rays_setup")
+            packed[:, 8:11] = vd
+    else:
+        rays_o, rays_d = rays
+        _need_gpu(rays_d, "rays")
+        sh = tuple(rays_d.shape)
+        ro, rd = _f32c(rays_o.reshape(-1, 3)), _f32c(rays_d.reshape(-1, 3))
+        N = rd.shape[0]
+        packed = torch.empty(N, 11, device=rd.device)
+        nf, ff = (near if not torch.is_tensor(near) else 0.), (far if not torch.is_tensor(far) else 1.)
+        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, int(bool(ndc)), float(nf), float(ff),
+                                      L.ptr(packed), L.stream()), "cfnerf_rays_setup")
+        if torch.is_tensor(near):
+            packed[:, 6] = near.reshape(-1).to(packed)
+        if torch.is_tensor(far):
+            packed[:, 7] = far.reshape(-1).to(packed)
+
+    all_ret = render_rays(packed, **kwargs)                                   # one launch (see docstring)
+    for k in all_ret:
+        if k != 'loss_entropy' and k != 'loss_entropy_uniformsample':         # RUN:163
+            all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'depth_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+# --------------------------------------------------------------------------------------------
+def create_nerf(args):
+    """Instantiate the CF-NeRF model (RUN:317-409).  Returns
+    ``(render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)``."""
+    args.embed_fn, args.input_ch = get_embedder(args.multires, args.i_embed)
+    args.input_ch_views = 0
+    args.embeddirs_fn = None
+    if args.use_viewdirs:
+        args.embeddirs_fn, args.input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    args.output_ch = 5 if args.N_importance > 0 else 4
+    args.skips = [args.netdepth / 2]                                          # RUN:327
+    if not hasattr(args, "device") or args.device is None:
+        args.device = torch.device("cuda")
+    model = _DataParallelShim(NeRF_Flows(args))
+    grad_vars = list(model.parameters())
+
+    def network_query_fn(inputs, viewdirs, network_fn, is_val, is_test):
+        m = _unwrap(network_fn)
+        eps = getattr(m, "_next_eps", None)
+        fn = (lambda x, iv, it: m(x, iv, it, eps_alpha=eps[:, 3:4], eps_rgb=eps[:, 0:3])) if eps is not None else network_fn
+        return run_network(inputs, viewdirs, fn, is_val, is_test, embed_fn=args.embed_fn,
+                           embeddirs_fn=args.embeddirs_fn, netchunk=args.netchunk_per_gpu * max(1, getattr(args, "n_gpus", 1)))
+    network_query_fn._cfnerf_fused = True        # render_rays may replace query + composite by the fused launch
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+
+    # checkpoints (RUN:345-378): newest '*tar*' in the log dir unless ft_path is given; keys filtered
+    # to those the model has; the optimiser state is NOT restored (commented out in the reference).
+    ckpts = []
+    if getattr(args, "ft_path", None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(args.basedir, args.dataname, args.type_flows, args.expname)
+        if os.path.isdir(d):
+            ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f]
+    if len(ckpts) > 0 and not args.no_reload:
+        if args.index_step == -1:
+            ckpt_path = ckpts[-1]
+        else:
+            ckpt_path = os.path.join(args.basedir, args.dataname, args.type_flows, args.expname,
+                                     '{:06d}_{:02d}.tar'.format(args.index_step, 1))
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        start = ckpt['global_step']
+        model_dict = model.state_dict()
+        pretrained = {k: v for k, v in ckpt['network_fn_state_dict'].items() if k in model_dict}
+        model_dict.update(pretrained)
+        model.load_state_dict(model_dict)
+    else:
+        print('No reloading')
+
+    render_kwargs_train = {
+        'is_train': args.is_train, 'uniformsample': args.uniformsample, 'network_query_fn': network_query_fn,
+        'perturb': args.perturb, 'N_importance': args.N_importance, 'N_samples': args.N_samples,
+        'K_samples': args.K_samples, 'network_fn': model, 'use_viewdirs': args.use_viewdirs,
+        'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:                            # RUN:397-400
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    render_kwargs_test['is_train'] = False
+    render_kwargs_test['uniformsample'] = False
+    render_kwargs_test['retraw'] = True
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer

@@ -1,0 +1,270 @@
+// cfnerf_abi.hip - the extern "C" boundary of libcfnerf_hip.so (see include/cfnerf.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "cfnerf_kernels.h"
+#include "cfnerf_model.h"
+
+using namespace cfnerf;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(CFNERF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int cfnerf_version(void) { return 100; }
+const char* cfnerf_last_error(void) { return g_err; }
+
+int64_t cfnerf_param_count(const cfnerf_cfg* cfg) {
+    if (!cfg) { fail(CFNERF_E_INVALID, "cfg is NULL"); return -1; }
+    if (const char* why = validate_cfg(*cfg)) { fail(CFNERF_E_UNSUPPORTED, "%s", why); return -1; }
+    return build_layout(*cfg).total;
+}
+
+int64_t cfnerf_param_offset(const cfnerf_cfg* cfg, const char* key, int64_t* numel) {
+    if (!cfg || !key) { fail(CFNERF_E_INVALID, "NULL argument"); return -1; }
+    if (const char* why = validate_cfg(*cfg)) { fail(CFNERF_E_UNSUPPORTED, "%s", why); return -1; }
+    ParamLayout L = build_layout(*cfg);
+    const ParamEntry* e = L.find(key);
+    if (!e) { fail(CFNERF_E_INVALID, "unknown parameter key '%s'", key); return -1; }
+    if (numel) *numel = e->numel();
+    return e->off;
+}
+
+const char* cfnerf_param_key(const cfnerf_cfg* cfg, int index) {
+    static thread_local std::string key;
+    if (!cfg || validate_cfg(*cfg)) return nullptr;
+    ParamLayout L = build_layout(*cfg);
+    if (index < 0 || index >= (int)L.e.size()) return nullptr;
+    key = L.e[index].key;
+    return key.c_str();
+}
+
+int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
+    if (!cfg || !out) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (const char* why = validate_cfg(*cfg)) return fail(CFNERF_E_UNSUPPORTED, "%s", why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(CFNERF_E_HIP, "no HIP device visible: the CF-NeRF hot path has no CPU fallback");
+    cfnerf_model* m = new (std::nothrow) cfnerf_model();
+    if (!m) return fail(CFNERF_E_NOMEM, "host allocation failed");
+    m->cfg = *cfg;
+    m->layout = build_layout(*cfg);
+    m->plan = build_pack_plan(*cfg, m->layout);
+    HIPCHK(hipGetDevice(&m->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, m->device));
+    m->n_cu = prop.multiProcessorCount;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = prop.gcnArchName;
+        delete m;
+        return fail(CFNERF_E_UNSUPPORTED, "device is %s; this library is built for gfx950 (MI355X) only", arch.c_str());
+    }
+    const size_t pbytes = (size_t)m->plan.tab.packed_floats * sizeof(float);
+    HIPCHK(hipMalloc(&m->d_packed, pbytes));
+    HIPCHK(hipMemset(m->d_packed, 0, pbytes));
+    HIPCHK(hipMalloc(&m->d_tab, sizeof(NetTab)));
+    HIPCHK(hipMemcpy(m->d_tab, &m->plan.tab, sizeof(NetTab), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
+    HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
+    HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
+    HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
+    HIPCHK(hipMalloc(&m->d_scratch_ent, sizeof(float)));
+    for (int i = 0; i < kNumTimers; ++i) {
+        HIPCHK(hipEventCreate(&m->ev0[i]));
+        HIPCHK(hipEventCreate(&m->ev1[i]));
+    }
+    m->ws_bytes = pbytes + sizeof(NetTab);
+    *out = m;
+    return CFNERF_OK;
+}
+
+int cfnerf_model_destroy(cfnerf_model* m) {
+    if (!m) return CFNERF_OK;
+    hipDeviceSynchronize();
+    hipFree(m->d_packed); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
+    hipFree(m->d_eps); hipFree(m->d_scratch_ent);
+    m->stash.release();
+    for (void* p : m->owned) hipFree(p);
+    for (int i = 0; i < kNumTimers; ++i) { hipEventDestroy(m->ev0[i]); hipEventDestroy(m->ev1[i]); }
+    delete m;
+    return CFNERF_OK;
+}
+
+int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s) {
+    if (!m || !flat_params) return fail(CFNERF_E_INVALID, "NULL argument");
+    m->flat = flat_params;
+    HIPCHK(launch_pack(flat_params, m->d_packed, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
+int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host, const float* rays_o, const float* rays_d,
+                      int64_t N, int ndc, float near_, float far_, float* rays, cfnerf_stream s) {
+    if (!rays || N < 0) return fail(CFNERF_E_INVALID, "bad rays/N");
+    if (N == 0) return CFNERF_OK;
+    RaysC2W c{};
+    if (c2w_host) {
+        if (N != (int64_t)H * W) return fail(CFNERF_E_INVALID, "c2w given: N (%lld) must equal H*W (%lld)", (long long)N, (long long)H * W);
+        std::memcpy(c.m, c2w_host, sizeof c.m);
+    } else if (!rays_o || !rays_d) {
+        return fail(CFNERF_E_INVALID, "either c2w_host or rays_o/rays_d must be given");
+    }
+    HIPCHK(launch_rays_setup(H, W, focal, c, c2w_host ? 1 : 0, rays_o, rays_d, N, ndc, near_, far_, rays, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
+static int check_common(cfnerf_model* m, int K) {
+    if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
+    if (!m->flat) return fail(CFNERF_E_INVALID, "cfnerf_model_set_params has not been called");
+    if (K < 1 || K > kMaxK) return fail(CFNERF_E_UNSUPPORTED, "K_samples must be in [1,%d], got %d", kMaxK, K);
+    return CFNERF_OK;
+}
+
+int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand, const float* eps,
+                      int64_t N, int S, int K, int flags, float* rgb_map, float* disp_map, float* depth_map,
+                      float* raw_opt, float* weights_opt, float* pts_opt, float* entropy_out, cfnerf_stream s) {
+    if (int rc = check_common(m, K)) return rc;
+    if (!rays || !t_vals || !eps || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
+    if (N == 0) return CFNERF_OK;
+    hipStream_t st = (hipStream_t)s;
+    if (flags & CFNERF_F_STASH) flags |= CFNERF_F_TRAIN;
+    const bool train = flags & CFNERF_F_TRAIN;
+    if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
+    FwdArgs a{};
+    a.tab = m->d_tab; a.wp = m->d_packed; a.flat = m->flat;
+    a.rays = rays; a.t_vals = t_vals; a.t_rand = t_rand; a.eps = eps;
+    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
+    a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
+    a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt;
+    a.ent_partials = train ? m->d_ent_partials : nullptr;
+    if (flags & CFNERF_F_STASH) {
+        if (int rc = m->stash.ensure(m->cfg, N, S, K)) return fail(rc, "stash allocation failed (%lld points)", (long long)a.P);
+        Stash& q = m->stash;
+        a.st_enc = q.enc; a.st_gd = q.gd; a.st_h = q.h; a.st_feat = q.feat; a.st_v = q.v; a.st_ha = q.ha; a.st_hr = q.hr;
+        a.st_theta = q.theta; a.st_z = q.z;
+        if (!a.raw) a.raw = q.raw;
+        q.raw_used = a.raw;
+        HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true;
+    }
+    int grid = 0;
+    if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->n_cu, st, &grid));
+    if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
+    if (train)
+        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, st));
+    return CFNERF_OK;
+}
+
+int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags, float* raw,
+                       float* entropy_out, cfnerf_stream s) {
+    if (int rc = check_common(m, K)) return rc;
+    if (!x || !eps || !raw) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (flags & CFNERF_F_STASH) return fail(CFNERF_E_UNSUPPORTED, "STASH is only available through cfnerf_render_fwd");
+    if (P < 0) return fail(CFNERF_E_INVALID, "bad P");
+    if (P == 0) return CFNERF_OK;
+    const bool train = flags & CFNERF_F_TRAIN;
+    if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
+    hipStream_t st = (hipStream_t)s;
+    FwdArgs a{};
+    a.tab = m->d_tab; a.wp = m->d_packed; a.flat = m->flat;
+    a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
+    a.ent_partials = train ? m->d_ent_partials : nullptr;
+    int grid = 0;
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->n_cu, st, &grid));
+    if (train)
+        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out, st));
+    return CFNERF_OK;
+}
+
+int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K,
+                         int white_bkgd, float* rgb_map, float* disp_map, float* depth_map, float* weights_opt,
+                         cfnerf_stream s) {
+    if (!raw || !z_vals || !rays_d || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (N < 0 || S < 1 || K < 1) return fail(CFNERF_E_INVALID, "bad N/S/K");
+    if (N == 0) return CFNERF_OK;
+    HIPCHK(launch_composite(raw, z_vals, rays_d, N, S, K, white_bkgd, rgb_map, disp_map, depth_map, weights_opt, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
+int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m) { return m ? (int64_t)(m->ws_bytes + m->stash.bytes) : 0; }
+
+int cfnerf_timing_enable(cfnerf_model* m, int enable) {
+    if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
+    m->timing = enable != 0;
+    return CFNERF_OK;
+}
+
+float cfnerf_timing_last_ms(cfnerf_model* m, int which) {
+    if (!m || which < 0 || which >= kNumTimers || !m->timing) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(m->ev1[which]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, m->ev0[which], m->ev1[which]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+}  // extern "C"
+
+// ---- debug / test helpers (not part of include/cfnerf.h) ------------------------------------------
+extern "C" {
+// host-side packing with the same index map the device kernel uses (CPU tests of the operand layout)
+int64_t cfnerf_debug_packed_floats(const cfnerf_cfg* cfg) {
+    if (!cfg || validate_cfg(*cfg)) return -1;
+    ParamLayout L = build_layout(*cfg);
+    return build_pack_plan(*cfg, L).tab.packed_floats;
+}
+int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float* packed_host) {
+    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
+    ParamLayout L = build_layout(*cfg);
+    PackPlan P = build_pack_plan(*cfg, L);
+    std::memset(packed_host, 0, (size_t)P.tab.packed_floats * sizeof(float));
+    for (const PackDesc& d : P.descs) {
+        const uint32_t n = d.n_cols ? d.n_rows * d.n_cols : d.n_rows;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t src, dst;
+            pack_map(d, i, &src, &dst);
+            packed_host[dst] = flat_host[src];
+        }
+    }
+    return CFNERF_OK;
+}
+// operand table entry by name: out[4] = {w_off, b_off, kc, nt}
+int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
+    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
+    ParamLayout L = build_layout(*cfg);
+    PackPlan P = build_pack_plan(*cfg, L);
+    const NetTab& T = P.tab;
+    const SubL* s = nullptr;
+    std::string n = name;
+    if (n == "trunk") s = &T.trunk[index]; else if (n == "skipseg") s = &T.skipseg; else if (n == "ha") s = &T.ha;
+    else if (n == "ft") s = &T.ft; else if (n == "vf") s = &T.vf; else if (n == "vd") s = &T.vd; else if (n == "hr") s = &T.hr;
+    else if (n == "fr") s = &T.fr; else if (n == "fa") s = &T.fa; else if (n == "bt_fr") s = &T.bt_fr;
+    else if (n == "bt_fa") s = &T.bt_fa; else if (n == "bt_hr") s = &T.bt_hr; else if (n == "bt_vf") s = &T.bt_vf;
+    else if (n == "bt_ft") s = &T.bt_ft; else if (n == "bt_ha") s = &T.bt_ha; else if (n == "bt_trunk") s = &T.bt_trunk[index];
+    if (!s) return CFNERF_E_INVALID;
+    out[0] = s->w_off; out[1] = s->b_off; out[2] = s->kc; out[3] = s->nt;
+    return CFNERF_OK;
+}
+}
+
+// ---- train-step entry points: implemented in cfnerf_bwd.hip -------------------------------------

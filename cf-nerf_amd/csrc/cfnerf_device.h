@@ -1,0 +1,219 @@
+// cfnerf_device.h - device-side building blocks shared by the forward and backward kernels.
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_32x32x2_f32 (exact fp32), LDS-resident activation tile.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cfnerf_layout.h"
+
+namespace cfnerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;          // 4 waves per workgroup
+constexpr int kWaves = 4;
+
+#define CFN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// lane id the optimiser cannot see through: address arithmetic derived from it stays at its use
+// instead of being hoisted out of the persistent tile loop (which spilt hundreds of registers).
+__device__ __forceinline__ int lane_id_opaque() {
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// activation row stride (floats): +4 keeps ds_read_b128 of 16 consecutive rows conflict-free
+// (row stride = 16 B mod 256 B) and rows 16-B aligned.  >= 128 so the theta tile fits.
+__host__ __device__ constexpr int act_ld(int W) { return (W > kThetaAll ? W : kThetaAll) + 4; }
+
+template <int NTW>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// 16*NV MFMAs of one k-chunk (8 k values): a0/a1 = A fragments of the two row tiles, b[j] = B fragments
+template <int NTW, int NV>
+__device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NTW], const f32x4 a0, const f32x4 a1, const f32x4 (&b)[NTW]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            acc[0][j] = CFN_MFMA(a0[c], b[j][c], acc[0][j]);
+            acc[1][j] = CFN_MFMA(a1[c], b[j][c], acc[1][j]);
+        }
+}
+
+// k-loop, unrolled by two with ping-pong operand registers: the loads of chunk k+1 are issued
+// before the MFMAs of chunk k, so L2 / LDS latency hides under a full block of MFMAs and no
+// register copies are needed.
+template <int NTW, int NV>
+__device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* const (&bp)[NTW], const float* a_ptr,
+                                         int lda, int KC) {
+    f32x4 bA[NTW], bB[NTW], a0A, a1A, a0B, a1B;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) bA[j] = bp[j][0];
+    a0A = *reinterpret_cast<const f32x4*>(a_ptr);
+    a1A = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda);
+    int kc = 0;
+    for (; kc + 1 < KC; kc += 2) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bB[j] = bp[j][(size_t)(kc + 1) * 64];
+        a0B = *reinterpret_cast<const f32x4*>(a_ptr + (kc + 1) * 8);
+        a1B = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda + (kc + 1) * 8);
+        mma_block<NTW, NV>(acc, a0A, a1A, bA);
+        const int k2 = (kc + 2 < KC) ? kc + 2 : KC - 1;       // clamped: the last prefetch re-reads valid data
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bA[j] = bp[j][(size_t)k2 * 64];
+        a0A = *reinterpret_cast<const f32x4*>(a_ptr + k2 * 8);
+        a1A = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda + k2 * 8);
+        mma_block<NTW, NV>(acc, a0B, a1B, bB);
+    }
+    if (kc < KC) mma_block<NTW, NV>(acc, a0A, a1A, bA);       // odd KC tail (operands already loaded)
+}
+
+// acc[i][j] += A[rows i*32..+31][0..8*kc) * B(tile nt0 + j*nts)       (one GEMM segment)
+//   A: LDS, row-major, stride lda floats, 64 rows.   B: packed operand `s` in global (L2-resident).
+// Lane l holds A[row l&31][k0 + 4*(l>>5) + c] and B[k0 + 4*(l>>5) + c][col l&31], c = 0..3:
+// one ds_read_b128 + one global_load_dwordx4 feed four MFMAs per tile.
+template <int NTW>
+__device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
+                                        const float* __restrict__ wp, const float* lds_a, int lda) {
+    const int lane = lane_id_opaque();
+    const int KC = s.kc;
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
+    if (nvalid == 0) return;
+    const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5);
+    const f32x4* bp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) nt = nt0;          // never dereferenced (j >= nvalid)
+        bp[j] = reinterpret_cast<const f32x4*>(wp + s.w_off) + (size_t)nt * KC * 64 + lane;
+    }
+    if (nvalid == NTW) { mma_loop<NTW, NTW>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 1 && nvalid == 1) { mma_loop<NTW, 1>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 2 && nvalid == 2) { mma_loop<NTW, (NTW > 2 ? 2 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 3 && nvalid == 3) { mma_loop<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+}
+
+// C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+enum { ACT_NONE = 0, ACT_RELU = 1 };
+
+// Write acc (+bias, activation) to the LDS tile (row-major, stride ld, column offset col0) and
+// optionally to a row-major global stash (stride gld) for rows < rows_valid.
+template <int NTW, int ACT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
+                                            const float* __restrict__ wp, float* lds_dst, int ld, int col0,
+                                            float* __restrict__ gdst, int gld, int rows_valid) {
+    const int lane = lane_id_opaque();
+    const int rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) continue;
+        const int col = nt * 32 + (lane & 31);
+        const float bv = (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
+        float* lp = lds_dst + rbase * ld + col0 + col;
+        float* gp = (gdst != nullptr) ? gdst + (size_t)rbase * gld + col : nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
+                float v = acc[i][j][r] + bv;
+                if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                lp[rr * ld] = v;
+                if (gp != nullptr && rr + rbase < rows_valid) gp[rr * gld] = v;
+            }
+    }
+}
+
+// ---- elementwise numerics: the same definitions torch uses on the reference path ---------------
+__device__ __forceinline__ float softplus_f(float x) {        // F.softplus(beta=1, threshold=20)
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// inclusive multiplicative scan across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(v, d, 64);
+        if (lane >= d) v *= t;
+    }
+    return v;
+}
+// inclusive additive scan from the HIGH lane down (suffix sum)
+__device__ __forceinline__ float wave_scan_add_rev(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_down(v, d, 64);
+        if (lane + d < 64) v += t;
+    }
+    return v;
+}
+
+// gamma(v): channel c of the encoding of a 3-vector (HLP:42-51): c<3 identity, then per
+// frequency f: sin(2^f v) x3, cos(2^f v) x3.  2^f * v is exact in fp32.
+__device__ __forceinline__ float enc_channel(const float* v, int c) {
+    if (c < 3) return v[c];
+    const int q = (c - 3) / 3, d = (c - 3) - 3 * q;       // q = 2*f + (0 sin | 1 cos)
+    const float a = v[d] * (float)(1 << (q >> 1));
+    return (q & 1) ? cosf(a) : sinf(a);
+}
+
+// ---- the conditional triangular Sylvester flows for one (point, latent sample) ------------------
+// th[84]: rgb D[(i*3+j)*4+f] | 36+ d1[i*4+f] | 48+ d2[i*4+f] | 60+ b[i*4+f] | 72+ alpha d1[f] | 76+ d2[f] | 80+ b[f]
+// (diagonals already tanh-ed, MOD:341-348).  z in/out: rgb (3) and alpha (1).  FLW:204-268, MOD:401-413.
+template <bool LOGDET>
+__device__ __forceinline__ void flows_fwd(const float (&th)[84], float (&z)[3], float& a, float& ld_rgb, float& ld_a) {
+    ld_rgb = 0.f; ld_a = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const bool odd = f & 1;
+        const float zp0 = odd ? z[2] : z[0], zp1 = z[1], zp2 = odd ? z[0] : z[2];
+        const float d2_0 = th[48 + 0 + f], d2_1 = th[48 + 4 + f], d2_2 = th[48 + 8 + f];
+        const float d1_0 = th[36 + 0 + f], d1_1 = th[36 + 4 + f], d1_2 = th[36 + 8 + f];
+        // R2[i][j>i] = D[j][i]  (full_d.transpose, MOD:375);  R1[i][j>i] = D[i][j] (MOD:374)
+        const float pre0 = ((d2_0 * zp0 + th[(1 * 3 + 0) * 4 + f] * zp1) + th[(2 * 3 + 0) * 4 + f] * zp2) + th[60 + 0 + f];
+        const float pre1 = (d2_1 * zp1 + th[(2 * 3 + 1) * 4 + f] * zp2) + th[60 + 4 + f];
+        const float pre2 = d2_2 * zp2 + th[60 + 8 + f];
+        const float t0 = tanhf(pre0), t1 = tanhf(pre1), t2 = tanhf(pre2);
+        const float u0 = (d1_0 * t0 + th[(0 * 3 + 1) * 4 + f] * t1) + th[(0 * 3 + 2) * 4 + f] * t2;
+        const float u1 = d1_1 * t1 + th[(1 * 3 + 2) * 4 + f] * t2;
+        const float u2 = d1_2 * t2;
+        z[0] = (odd ? u2 : u0) + z[0];
+        z[1] = u1 + z[1];
+        z[2] = (odd ? u0 : u2) + z[2];
+        const float ta = tanhf(th[76 + f] * a + th[80 + f]);
+        a = th[72 + f] * ta + a;
+        if (LOGDET) {
+            ld_rgb += (logf(fabsf((1.f - t0 * t0) * (d1_0 * d2_0) + 1.f) + 1e-08f) +
+                       logf(fabsf((1.f - t1 * t1) * (d1_1 * d2_1) + 1.f) + 1e-08f)) +
+                      logf(fabsf((1.f - t2 * t2) * (d1_2 * d2_2) + 1.f) + 1e-08f);
+            ld_a += logf(fabsf((1.f - ta * ta) * (th[72 + f] * th[76 + f]) + 1.f) + 1e-08f);
+        }
+    }
+}
+
+}  // namespace cfnerf

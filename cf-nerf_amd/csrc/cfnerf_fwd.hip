@@ -1,0 +1,543 @@
+// cfnerf_fwd.hip - fused forward of the CF-NeRF ray-batch path for gfx950 (MI355X).
+//
+// One workgroup (4 waves) owns a tile of 64 points: positional encoding -> 8-layer trunk ->
+// heads -> flow-parameter heads all run out of ONE LDS-resident activation tile (in place), the
+// dense layers on v_mfma_f32_32x32x2_f32 (exact fp32) with the weights streamed from L2 in
+// fragment order; then the K conditional flows and the alpha-composite run on the VALU with
+// wavefront scans.  In ray mode a workgroup walks whole rays (tiles of one ray are consecutive),
+// so `raw` never has to leave the chip.
+//
+// Reference functions replaced: render_rays RUN:457-553, run_network RUN:67-85, Embedder HLP:21-69,
+// NeRF_Flows.encode/forward MOD:165-291, TriangularSylvesterNeRF MOD:358-416, TriangularSylvester
+// FLW:189-268, raw2outputs RUN:411-454.
+#include "cfnerf_device.h"
+#include "cfnerf_kernels.h"
+
+namespace cfnerf {
+
+template <int W>
+struct FwdCfg {
+    static constexpr int NT = W / 32;                         // n tiles of a W-wide layer
+    static constexpr int NTW = (NT + kWaves - 1) / kWaves;    // per wave
+    static constexpr int NTV = (W / 64 + kWaves - 1) / kWaves;// views layer (W/2 wide)
+    static constexpr int LD = act_ld(W);
+};
+
+__host__ __device__ inline size_t fwd_lds_bytes(int W, int ha) {
+    // act[64][LD] | hs[64][ha+4] | rowinfo[65][4] (+pad) | gdir[32] | comp[kMaxK][8] | red[8]
+    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4) + 68 * 4 + 32 + kMaxK * 8 + 8);
+}
+
+__device__ __forceinline__ float zlin_f(float t, float nearv, float farv, bool lindisp) {
+    if (lindisp) return 1.f / ((1.f / nearv) * (1.f - t) + (1.f / farv) * t);       // RUN:514
+    return nearv * (1.f - t) + farv * t;                                            // RUN:512
+}
+
+// positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
+template <int MODE, int LD>
+__device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, const float* __restrict__ x, int64_t p0,
+                                            int rows_valid, int ic, int icv) {
+    const int tid = threadIdx.x;
+    if (MODE == 0) {
+        for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
+            const int row = idx & 63, c = idx >> 6;                 // a wave = one channel of 64 rows: no divergence
+            act[row * LD + c] = (c < ic) ? enc_channel(rowinfo + row * 4, c) : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
+            const int row = idx >> 6, c = idx & 63;
+            float v = 0.f;
+            if (c < ic && row < rows_valid) v = x[(p0 + row) * (int64_t)(ic + icv) + c];
+            act[row * LD + c] = v;
+        }
+    }
+}
+
+template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN>
+__global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
+void fused_fwd_kernel(const FwdArgs A) {
+    using C = FwdCfg<W>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NetTab& T = *A.tab;
+    const int HA = T.ha_sz, HR = T.hr_sz;
+    const int HLD = HA + 4;
+    float* act = smem;
+    float* hs = act + kTileM * LD;
+    float* rowinfo = hs + kTileM * HLD;       // [65][4]: x y z zval
+    float* gdir = rowinfo + 68 * 4;           // [32]
+    float* comp = gdir + 32;                  // [kMaxK][8]: r g b depth acc T _ _
+    float* red = comp + kMaxK * 8;            // [8]
+
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const float* __restrict__ wp = A.wp;
+    const int S = A.S, K = A.K;
+    const int ic = T.ic, icv = T.icv;
+    const int chunks_per_ray = (S + kTileM - 1) / kTileM;
+    const int64_t n_units = (MODE == 0) ? A.N : (A.P + kTileM - 1) / kTileM;
+
+    float ent_r_sum = 0.f, ent_a_sum = 0.f;   // per-lane partial sums of the log-det terms (TRAIN)
+
+    const float a_mean = A.flat[0], a_std = A.flat[1];
+    const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
+    const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
+
+    for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        float ro[3], rd[3], nearv = 0.f, farv = 1.f, dnorm = 0.f;
+        if (MODE == 0) {
+            const float* r = A.rays + unit * 11;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { ro[d] = r[d]; rd[d] = r[3 + d]; }
+            nearv = r[6]; farv = r[7];
+            dnorm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);   // torch.norm(rays_d) RUN:429
+            if (tid < 32) {
+                gdir[tid] = (tid < icv) ? enc_channel(r + 8, tid) : 0.f;
+            }
+            if (tid < K) {
+                float* c = comp + tid * 8;
+                c[0] = c[1] = c[2] = c[3] = c[4] = 0.f; c[5] = 1.f;
+            }
+        }
+        const int n_chunks = (MODE == 0) ? chunks_per_ray : 1;
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            // global point index of row 0 and number of valid rows of this tile
+            const int64_t p0 = (MODE == 0) ? unit * (int64_t)S + (int64_t)chunk * kTileM : unit * (int64_t)kTileM;
+            const int rows_valid = (MODE == 0) ? min(kTileM, S - chunk * kTileM) : (int)min((int64_t)kTileM, A.P - p0);
+
+            // ---- 1. sampling along the ray (RUN:510-534): z for rows 0..64, pts for rows 0..63
+            if (MODE == 0) {
+                if (tid <= kTileM) {
+                    const int s = chunk * kTileM + tid;
+                    float zv = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+                    if (s < S) {
+                        const bool lind = (A.flags & CFNERF_F_LINDISP) != 0;
+                        const float zc = zlin_f(A.t_vals[s], nearv, farv, lind);
+                        zv = zc;
+                        if (A.t_rand != nullptr) {                                                 // RUN:518-532
+                            const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(A.t_vals[s + 1], nearv, farv, lind) + zc);
+                            const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(A.t_vals[s - 1], nearv, farv, lind));
+                            zv = lower + (upper - lower) * A.t_rand[unit * (int64_t)S + s];
+                        }
+                        px = ro[0] + rd[0] * zv; py = ro[1] + rd[1] * zv; pz = ro[2] + rd[2] * zv;  // RUN:534
+                        if (tid < kTileM) {
+                            if (A.pts != nullptr) {
+                                float* o = A.pts + (unit * (int64_t)S + s) * 3;
+                                o[0] = px; o[1] = py; o[2] = pz;
+                            }
+                            if (A.st_z != nullptr) A.st_z[unit * (int64_t)S + s] = zv;
+                        }
+                    }
+                    float* ri = rowinfo + tid * 4;
+                    ri[0] = px; ri[1] = py; ri[2] = pz; ri[3] = zv;
+                }
+                __syncthreads();
+            }
+
+            // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
+            encode_tile<MODE, LD>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
+            if (A.st_enc != nullptr) {
+                __syncthreads();
+                for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
+                    const int row = idx >> 6, c = idx & 63;
+                    if (row < rows_valid) A.st_enc[(p0 + row) * 64 + c] = act[row * LD + c];
+                }
+            }
+            __syncthreads();
+
+            // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
+            for (int l = 0; l < T.D; ++l) {
+                f32x16 acc[2][C::NTW];
+                acc_zero(acc);
+                mma_seg<C::NTW>(acc, T.trunk[l], wave, kWaves, wp, act, LD);
+                if (l >= 1 && l - 1 == T.skip) {
+                    __syncthreads();                 // every wave is done reading h_{l-1}
+                    encode_tile<MODE, LD>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
+                    __syncthreads();
+                    mma_seg<C::NTW>(acc, T.skipseg, wave, kWaves, wp, act, LD);
+                }
+                __syncthreads();
+                float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
+                store_tiles<C::NTW, ACT_RELU>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid);
+                __syncthreads();
+            }
+
+            // ---- 4. heads: h_alpha = A h (MOD:175), feature = F h (MOD:176)
+            {
+                f32x16 accF[2][C::NTW];
+                f32x16 accA[2][1];
+                acc_zero(accF); acc_zero(accA);
+                mma_seg<1>(accA, T.ha, wave, kWaves, wp, act, LD);
+                mma_seg<C::NTW>(accF, T.ft, wave, kWaves, wp, act, LD);
+                __syncthreads();
+                store_tiles<1, ACT_NONE>(accA, T.ha, wave, kWaves, wp, hs, HLD, 0,
+                                         A.st_ha ? A.st_ha + p0 * HA : nullptr, HA, rows_valid);
+                store_tiles<C::NTW, ACT_NONE>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
+                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
+                __syncthreads();
+            }
+            // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
+            {
+                f32x16 acc[2][C::NTV];
+                acc_zero(acc);
+                mma_seg<C::NTV>(acc, T.vf, wave, kWaves, wp, act, LD);
+                __syncthreads();
+                for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
+                    const int row = idx >> 5, c = idx & 31;
+                    float v;
+                    if (MODE == 0) v = gdir[c];
+                    else v = (c < icv && row < rows_valid) ? A.x[(p0 + row) * (int64_t)(ic + icv) + ic + c] : 0.f;
+                    act[row * LD + c] = v;
+                    if (A.st_gd != nullptr && row < rows_valid) A.st_gd[(p0 + row) * 32 + c] = v;
+                }
+                __syncthreads();
+                mma_seg<C::NTV>(acc, T.vd, wave, kWaves, wp, act, LD);
+                __syncthreads();
+                store_tiles<C::NTV, ACT_RELU>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
+                                              A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid);
+                __syncthreads();
+            }
+            // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
+            {
+                f32x16 acc[2][1];
+                acc_zero(acc);
+                mma_seg<1>(acc, T.hr, wave, kWaves, wp, act, LD);
+                __syncthreads();
+                store_tiles<1, ACT_NONE>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
+                                         A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
+                __syncthreads();
+            }
+            // ---- 7. amortised flow parameters (MOD:366-383), once per point (the reference recomputes
+            //         them K times on duplicated rows, MOD:210-217): theta -> act[:, 0:128)
+            {
+                f32x16 acc[2][1];
+                acc_zero(acc);
+                const bool is_rgb = wave < 3;
+                if (is_rgb) mma_seg<1>(acc, T.fr, wave, kWaves, wp, act + W / 2, LD);
+                else        mma_seg<1>(acc, T.fa, 0, kWaves, wp, hs, HLD);
+                __syncthreads();
+                const SubL s = is_rgb ? T.fr : T.fa;
+                const int nt = is_rgb ? wave : 0;
+                const int colb = is_rgb ? wave * 32 : kThetaRgb;
+                const int lo = lane_id_opaque();
+                const int cl = lo & 31, rbase = 4 * (lo >> 5);
+                const int c_local = is_rgb ? colb + cl : cl;          // column inside the rgb / alpha head block
+                const float bv = wp[s.b_off + nt * 32 + cl];
+                const int F = 4;
+                const bool tanh_col = is_rgb ? (c_local >= 9 * F && c_local < 15 * F) : (c_local < 2 * F);
+                float* lp = act + rbase * LD + colb + cl;
+                float* gp = (A.st_theta != nullptr) ? A.st_theta + (p0 + rbase) * kThetaAll + colb + cl : nullptr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][0][r] + bv;
+                        if (tanh_col) v = tanhf(v);                   // diag_activation, MOD:337-348
+                        lp[rr * LD] = v;
+                        if (gp != nullptr && rr + rbase < rows_valid) gp[rr * kThetaAll] = v;
+                    }
+                __syncthreads();
+            }
+            // ---- 8. flows + composite: lane = sample (row), waves stride over the K latent samples
+            {
+                const int row = lane_id_opaque();
+                const bool valid = row < rows_valid;
+                float th[84];
+                {
+                    const f32x4* tp = reinterpret_cast<const f32x4*>(act + row * LD);
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) {
+                        const f32x4 v = tp[q];
+                        th[q * 4 + 0] = v[0]; th[q * 4 + 1] = v[1]; th[q * 4 + 2] = v[2]; th[q * 4 + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const f32x4 v = tp[kThetaRgb / 4 + q];
+                        th[72 + q * 4 + 0] = v[0]; th[72 + q * 4 + 1] = v[1]; th[72 + q * 4 + 2] = v[2]; th[72 + q * 4 + 3] = v[3];
+                    }
+                }
+                float zval = 0.f, dist = 0.f;
+                if (MODE == 0) {
+                    zval = rowinfo[row * 4 + 3];
+                    const int s = chunk * kTileM + row;
+                    const float dz = (s == S - 1) ? 1e1f : rowinfo[(row + 1) * 4 + 3] - zval;      // RUN:426-427
+                    dist = dz * dnorm;                                                             // RUN:429
+                }
+                for (int k = wave; k < K; k += kWaves) {
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+                    float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
+                    float a = e[3] * a_std + a_mean;                                               // MOD:200/239
+                    float ldr, lda;
+                    flows_fwd<TRAIN>(th, z, a, ldr, lda);
+                    if (A.raw != nullptr && valid) {
+                        f32x4 o; o[0] = z[0]; o[1] = z[1]; o[2] = z[2]; o[3] = a;
+                        *reinterpret_cast<f32x4*>(A.raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
+                    }
+                    const float sp_a = softplus_f(a);
+                    if (TRAIN && valid) {
+                        ent_a_sum += lda + (a - sp_a);                                                        // MOD:263
+                        ent_r_sum += ldr + (((z[0] + z[1]) + z[2]) - 2.f * ((softplus_f(z[0]) + softplus_f(z[1])) + softplus_f(z[2])));  // MOD:278
+                    }
+                    if (MODE == 0) {
+                        const float alpha = valid ? 1.f - expf(-sp_a * dist) : 0.f;                // RUN:424,442
+                        const float xk = (1.f - alpha) + 1e-10f;                                   // RUN:443
+                        const float incl = wave_scan_mul(xk);
+                        float excl = __shfl_up(incl, 1, 64);
+                        if (lane == 0) excl = 1.f;
+                        float* cp = comp + k * 8;
+                        const float Tcar = cp[5];
+                        const float wgt = alpha * (Tcar * excl);
+                        if (A.weights != nullptr && valid) A.weights[(p0 + row) * (int64_t)K + k] = wgt;
+                        const float s0 = wave_sum(wgt * sigmoid_f(z[0]));                          // RUN:431,444
+                        const float s1 = wave_sum(wgt * sigmoid_f(z[1]));
+                        const float s2 = wave_sum(wgt * sigmoid_f(z[2]));
+                        const float sd = wave_sum(wgt * zval);                                     // RUN:447
+                        const float sa = wave_sum(wgt);                                            // RUN:449
+                        const float tot = __shfl(incl, 63, 64);
+                        if (lane == 0) {
+                            cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar * tot;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }  // chunks
+
+        if (MODE == 0 && tid < K) {
+            const float* cp = comp + tid * 8;
+            const int k = tid;
+            float r0 = cp[0], r1 = cp[1], r2 = cp[2];
+            const float depth = cp[3], acc = cp[4];
+            if (A.flags & CFNERF_F_WHITE_BKGD) { r0 = r0 + (1.f - acc); r1 = r1 + (1.f - acc); r2 = r2 + (1.f - acc); }  // RUN:451-452
+            const float disp = 1.f / fmaxf(1e-10f + 1e-10f, depth / (acc + 1e-10f) + 1e-10f);                    // RUN:448
+            float* o = A.rgb_map + unit * 3 * (int64_t)K;
+            o[0 * K + k] = r0; o[1 * K + k] = r1; o[2 * K + k] = r2;                                               // [N,3,K] RUN:445
+            A.disp[unit * (int64_t)K + k] = disp;
+            A.depth[unit * (int64_t)K + k] = depth;
+        }
+        __syncthreads();
+    }  // units
+
+    if (TRAIN && A.ent_partials != nullptr) {
+        const float sr = wave_sum(ent_r_sum), sa = wave_sum(ent_a_sum);
+        if (lane == 0) { red[wave * 2] = sr; red[wave * 2 + 1] = sa; }
+        __syncthreads();
+        if (tid == 0) {
+            A.ent_partials[blockIdx.x * 2 + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+            A.ent_partials[blockIdx.x * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+        }
+    }
+}
+
+// loss_entropy = mean(base_a) - mean(ld_a) + mean(base_rgb) - mean(ld_rgb)      (MOD:268,283,286)
+__global__ void entropy_finalize_kernel(const float* partials, int n_part, const float* flat, const float* eps,
+                                        int K, double count /* P*K */, float* out) {
+    __shared__ double sh[2][256];
+    double s0 = 0, s1 = 0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) { s0 += partials[2 * i]; s1 += partials[2 * i + 1]; }
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { sh[0][threadIdx.x] += sh[0][threadIdx.x + d]; sh[1][threadIdx.x] += sh[1][threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float a_mean = flat[0], a_std = flat[1];
+        float base_a = 0.f, base_r = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float a0 = eps[k * 4 + 3] * a_std + a_mean;
+            base_a += -0.5f * (logf(a_std) * 2.f + (a0 - a_mean) * (a0 - a_mean) * (1.f / (a_std * a_std)));
+            for (int c = 0; c < 3; ++c) {
+                const float m = flat[2 + c], sd = flat[5 + c];
+                const float r0 = eps[k * 4 + c] * sd + m;
+                base_r += -0.5f * (logf(sd) * 2.f + (r0 - m) * (r0 - m) * (1.f / (sd * sd)));
+            }
+        }
+        const double ent = (double)base_a / K - sh[1][0] / count + (double)base_r / (3.0 * K) - sh[0][0] / count;
+        out[0] = (float)ent;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone composite (raw2outputs RUN:411-454): one wave per ray, lane = sample, loop over k.
+// HBM-bound: reads 16*S*K + 4*S + 12 bytes per ray, writes 20*K (+4*S*K for weights).
+__global__ __launch_bounds__(kThreads)
+void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+                      int64_t N, int S, int K, int white_bkgd, float* rgb_map, float* disp_map, float* depth_map,
+                      float* weights) {
+    const int lane = lane_id();
+    const int64_t ray = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const float* d = rays_d + ray * 3;
+    const float dnorm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zr = z_vals + ray * (int64_t)S;
+    const int nch = (S + 63) / 64;
+    for (int k = 0; k < K; ++k) {
+        float car = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, aa = 0.f;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int s = ch * 64 + lane;
+            const bool valid = s < S;
+            float zv = 0.f, dist = 0.f;
+            f32x4 rv; rv[0] = rv[1] = rv[2] = rv[3] = 0.f;
+            if (valid) {
+                zv = zr[s];
+                const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
+                dist = dz * dnorm;
+                rv = *reinterpret_cast<const f32x4*>(raw + ((ray * S + s) * (int64_t)K + k) * 4);
+            }
+            const float alpha = valid ? 1.f - expf(-softplus_f(rv[3]) * dist) : 0.f;
+            const float xk = (1.f - alpha) + 1e-10f;
+            const float incl = wave_scan_mul(xk);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.f;
+            const float wgt = alpha * (car * excl);
+            if (weights != nullptr && valid) weights[(ray * S + s) * (int64_t)K + k] = wgt;
+            a0 += wave_sum(wgt * sigmoid_f(rv[0]));
+            a1 += wave_sum(wgt * sigmoid_f(rv[1]));
+            a2 += wave_sum(wgt * sigmoid_f(rv[2]));
+            ad += wave_sum(wgt * zv);
+            aa += wave_sum(wgt);
+            car *= __shfl(incl, 63, 64);
+        }
+        if (lane == 0) {
+            if (white_bkgd) { a0 = a0 + (1.f - aa); a1 = a1 + (1.f - aa); a2 = a2 + (1.f - aa); }
+            float* o = rgb_map + ray * 3 * (int64_t)K;
+            o[0 * K + k] = a0; o[1 * K + k] = a1; o[2 * K + k] = a2;
+            disp_map[ray * (int64_t)K + k] = 1.f / fmaxf(1e-10f + 1e-10f, ad / (aa + 1e-10f) + 1e-10f);
+            depth_map[ray * (int64_t)K + k] = ad;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray set-up (render() RUN:129-158; get_rays HLP:288-297; ndc_rays HLP:360-377)
+__global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int use_c2w, const float* rays_o,
+                                  const float* rays_d, int64_t N, int ndc, float nearv, float farv, float* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float o[3], d[3];
+    if (use_c2w) {
+        const int j = (int)(n / Wd), i = (int)(n - (int64_t)j * Wd);                 // row-major pixels, i = x (HLP:289-291)
+        const float dir[3] = {((float)i - (float)Wd * .5f) / focal, -((float)j - (float)H * .5f) / focal, -1.f};   // HLP:292
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            d[r] = (dir[0] * c2w.m[r * 4 + 0] + dir[1] * c2w.m[r * 4 + 1]) + dir[2] * c2w.m[r * 4 + 2];           // HLP:294
+            o[r] = c2w.m[r * 4 + 3];                                                                              // HLP:296
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { o[r] = rays_o[n * 3 + r]; d[r] = rays_d[n * 3 + r]; }
+    }
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float vd[3] = {d[0] / nrm, d[1] / nrm, d[2] / nrm};                                                     // RUN:143
+    if (ndc) {
+        const float nr = 1.f;                                                                                     // RUN:149
+        const float t = -(nr + o[2]) / d[2];                                                                      // HLP:362
+        o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];                                   // HLP:363
+        const float cw = -1.f / ((float)Wd / (2.f * focal)), chh = -1.f / ((float)H / (2.f * focal));
+        const float o0 = cw * o[0] / o[2], o1 = chh * o[1] / o[2], o2 = 1.f + 2.f * nr / o[2];                    // HLP:366-368
+        const float d0 = cw * (d[0] / d[2] - o[0] / o[2]);                                                        // HLP:370
+        const float d1 = chh * (d[1] / d[2] - o[1] / o[2]);
+        const float d2 = -2.f * nr / o[2];
+        o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
+    }
+    float* r = out + n * 11;
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = nearv; r[7] = farv; r[8] = vd[0]; r[9] = vd[1]; r[10] = vd[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: flat state_dict-ordered parameters -> fragment-ordered operands (cfnerf_layout.h)
+__global__ void pack_kernel(const float* __restrict__ flat, float* __restrict__ packed, const PackDesc* __restrict__ descs,
+                            int ndesc, uint32_t total) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_elem <= idx) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    uint32_t src, dst;
+    pack_map(d, idx - d.first_elem, &src, &dst);
+    packed[dst] = flat[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+static int max_blocks_per_cu(const void* fn, size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kThreads, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+template <int W, int MODE, bool TRAIN>
+static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hipStream_t st, int* grid_out) {
+    auto fn = fused_fwd_kernel<W, MODE, TRAIN>;
+    const size_t lds = fwd_lds_bytes(W, ht.ha_sz);
+    static size_t lds_set = 0;
+    static int per_cu = 0;
+    if (lds_set != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        per_cu = max_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
+        if (per_cu > 2) per_cu = 2;
+        lds_set = lds;
+    }
+    const int64_t units = (MODE == 0) ? a.N : (a.P + kTileM - 1) / kTileM;
+    int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, bool train, int n_cu, hipStream_t st, int* grid_out) {
+    if (mode == 0) return train ? launch_fwd_t<W, 0, true>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false>(a, ht, n_cu, st, grid_out);
+    return train ? launch_fwd_t<W, 1, true>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false>(a, ht, n_cu, st, grid_out);
+}
+
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int n_cu, hipStream_t st, int* grid_out) {
+    switch (ht.W) {
+        case 64: return launch_fwd_w<64>(a, ht, mode, train, n_cu, st, grid_out);
+        case 128: return launch_fwd_w<128>(a, ht, mode, train, n_cu, st, grid_out);
+        case 256: return launch_fwd_w<256>(a, ht, mode, train, n_cu, st, grid_out);
+        case 512: return launch_fwd_w<512>(a, ht, mode, train, n_cu, st, grid_out);
+    }
+    return hipErrorInvalidValue;
+}
+
+int fused_fwd_max_grid(int W, int ha, int n_cu) {
+    // upper bound of the grid used by launch_fused_fwd (for sizing the entropy partial buffer)
+    (void)W; (void)ha;
+    return n_cu * 2;
+}
+
+hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
+                                   double count, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(256), 0, st, partials, n_part, flat, eps, K, count, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(const float* raw, const float* z, const float* d, int64_t N, int S, int K, int wb,
+                            float* rgb, float* disp, float* depth, float* weights, hipStream_t st) {
+    const int grid = (int)((N + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(composite_kernel, dim3(grid), dim3(kThreads), 0, st, raw, z, d, N, S, K, wb, rgb, disp, depth, weights);
+    return hipGetLastError();
+}
+
+hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
+                             int64_t N, int ndc, float nearv, float farv, float* out, hipStream_t st) {
+    const int grid = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(rays_setup_kernel, dim3(grid), dim3(256), 0, st, H, Wd, focal, c2w, use_c2w, ro, rd, N, ndc, nearv, farv, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const float* flat, float* packed, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st) {
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, flat, packed, descs, ndesc, total);
+    return hipGetLastError();
+}
+
+}  // namespace cfnerf

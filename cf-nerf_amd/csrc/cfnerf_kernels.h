@@ -1,0 +1,42 @@
+// cfnerf_kernels.h - kernel argument blocks and host launchers (internal to libcfnerf_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "cfnerf_layout.h"
+
+namespace cfnerf {
+
+struct RaysC2W { float m[12]; };
+
+struct FwdArgs {
+    const NetTab* tab;        // device copy of the operand table
+    const float* wp;          // packed operands
+    const float* flat;        // flat parameters (base-Gaussian mean/std live at [0,8))
+    const float* rays;        // [N,11]         (ray mode)
+    const float* t_vals;      // [S]
+    const float* t_rand;      // [N,S] or null
+    const float* eps;         // [K,4]
+    const float* x;           // [P,90]         (points mode)
+    int64_t N, P;             // rays, points (P = N*S in ray mode)
+    int32_t S, K, flags;
+    float *rgb_map, *disp, *depth;       // [N,3,K] [N,K] [N,K]
+    float *raw, *weights, *pts;          // optional [P,K,4] [P,K] [P,3]
+    float* ent_partials;                 // [grid,2]  (TRAIN)
+    // activation stash for the backward pass (all optional, row-major per point)
+    float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
+};
+
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int n_cu, hipStream_t st, int* grid_out);
+int fused_fwd_max_grid(int W, int ha, int n_cu);
+hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
+                                   double count, float* out, hipStream_t st);
+hipError_t launch_composite(const float* raw, const float* z, const float* d, int64_t N, int S, int K, int wb,
+                            float* rgb, float* disp, float* depth, float* weights, hipStream_t st);
+hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
+                             int64_t N, int ndc, float nearv, float farv, float* out, hipStream_t st);
+hipError_t launch_pack(const float* flat, float* packed, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
+
+}  // namespace cfnerf

@@ -1,0 +1,270 @@
+// cfnerf_layout.h - host-side description of the flat parameter layout and of the packed
+// (MFMA-fragment-ordered) weight buffer.  Shared by every translation unit of libcfnerf_hip.so.
+//
+// Flat layout = NeRF_Flows.state_dict() order (reference model/models.py:38-67, 339-350),
+// nn.Linear weights row-major [out, in].
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cfnerf.h"
+
+namespace cfnerf {
+
+constexpr int kMaxDepth = 16;
+constexpr int kTileM = 64;            // rows (points) per workgroup tile
+constexpr int kMaxK = 64;             // latent samples per point supported by the fused kernels
+
+struct ParamEntry {
+    std::string key;
+    int64_t off;                      // floats
+    int64_t rows, cols;               // cols == 0 -> vector of `rows`
+    int64_t numel() const { return cols ? rows * cols : rows; }
+};
+
+struct ParamLayout {
+    std::vector<ParamEntry> e;
+    int64_t total = 0;
+    const ParamEntry* find(const char* key) const {
+        for (auto& x : e) if (x.key == key) return &x;
+        return nullptr;
+    }
+    int64_t off(const char* key) const { auto* p = find(key); return p ? p->off : -1; }
+};
+
+inline int enc_ch(int multires) { return 3 + 6 * multires; }
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// returns nullptr when valid, else the reason
+inline const char* validate_cfg(const cfnerf_cfg& c) {
+    if (c.netdepth < 2 || c.netdepth > kMaxDepth) return "netdepth must be in [2,16]";
+    if (c.netwidth != 64 && c.netwidth != 128 && c.netwidth != 256 && c.netwidth != 512)
+        return "netwidth must be 64, 128, 256 or 512";
+    if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";
+    if (c.multires_views < 1 || enc_ch(c.multires_views) > 32) return "multires_views must be in [1,4]";
+    if (c.h_alpha_size % 8 || c.h_alpha_size < 8 || c.h_alpha_size > 64) return "h_alpha_size must be a multiple of 8 in [8,64]";
+    if (c.h_rgb_size % 8 || c.h_rgb_size < 8 || c.h_rgb_size > 64) return "h_rgb_size must be a multiple of 8 in [8,64]";
+    if (c.n_flows != 4) return "only n_flows == 4 is built";
+    return nullptr;
+}
+
+inline ParamLayout build_layout(const cfnerf_cfg& c) {
+    ParamLayout L;
+    const int W = c.netwidth, D = c.netdepth, ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), F = c.n_flows;
+    const int skip = D / 2;           // RUN:327 args.skips = [netdepth / 2]
+    auto add = [&](const std::string& k, int64_t r, int64_t cc) {
+        ParamEntry p{k, L.total, r, cc};
+        L.total += p.numel();
+        L.e.push_back(p);
+    };
+    add("alpha_mean", 1, 0); add("alpha_std", 1, 0); add("rgb_mean", 3, 0); add("rgb_std", 3, 0);
+    for (int i = 0; i < D; ++i) {
+        int k = (i == 0) ? ic : ((i - 1) == skip ? W + ic : W);          // MOD:39
+        add("pts_linears." + std::to_string(i) + ".weight", W, k);
+        add("pts_linears." + std::to_string(i) + ".bias", W, 0);
+    }
+    add("views_linears.0.weight", W / 2, icv + W); add("views_linears.0.bias", W / 2, 0);
+    add("feature_linear.weight", W, W);            add("feature_linear.bias", W, 0);
+    add("alpha_linear.weight", 1, W);              add("alpha_linear.bias", 1, 0);          // dead (MOD:59)
+    add("alpha_std_linear.weight", 1, W);          add("alpha_std_linear.bias", 1, 0);      // dead (MOD:60)
+    add("h_alpha_linear.weight", c.h_alpha_size, W);   add("h_alpha_linear.bias", c.h_alpha_size, 0);
+    add("h_rgb_linear.weight", c.h_rgb_size, W / 2);   add("h_rgb_linear.bias", c.h_rgb_size, 0);
+    const char* names[2] = {"flows_rgb", "flows_alpha"};
+    const int zs[2] = {3, 1};
+    const int hs[2] = {c.h_rgb_size, c.h_alpha_size};
+    for (int t = 0; t < 2; ++t) {
+        std::string n = names[t];
+        int z = zs[t];
+        add(n + ".amor_d.weight", F * z * z, hs[t]);     add(n + ".amor_d.bias", F * z * z, 0);
+        add(n + ".amor_diag1.0.weight", F * z, hs[t]);   add(n + ".amor_diag1.0.bias", F * z, 0);
+        add(n + ".amor_diag2.0.weight", F * z, hs[t]);   add(n + ".amor_diag2.0.bias", F * z, 0);
+        add(n + ".amor_b.weight", F * z, hs[t]);         add(n + ".amor_b.bias", F * z, 0);
+    }
+    return L;
+}
+
+// One packed GEMM operand: B fragments of an [N_out x K_red] matrix for v_mfma_f32_32x32x2_f32.
+//   packed[((nt * kc_count + kc) * 64 + lane) * 4 + c] = M[nt*32 + (lane & 31)][kc*8 + 4*(lane >> 5) + c]
+// (zero outside the valid range).  A float4 per lane feeds 4 MFMAs; the A operand uses the same
+// k assignment, so the order of k inside a chunk is free.
+struct SubL {
+    uint32_t w_off;      // floats, into the packed buffer
+    uint32_t b_off;      // floats, padded bias (nt*32 entries); 0xffffffff = none
+    uint16_t kc;         // k chunks of 8
+    uint16_t nt;         // n tiles of 32
+};
+
+// theta (flow-parameter) column map inside a tile row: rgb heads [0,96), alpha heads [96,128)
+//   rgb:   [0,9F) amor_d (i*3+j)*F+f | [9F,12F) diag1 i*F+f | [12F,15F) diag2 | [15F,18F) b
+//   alpha: 96 + [0,F) diag1 | [F,2F) diag2 | [2F,3F) b         (amor_d of z=1 is fully masked: MOD:327,374)
+constexpr int kThetaRgb = 96;
+constexpr int kThetaAll = 128;
+
+struct NetTab {
+    // forward
+    SubL trunk[kMaxDepth];   // trunk[0]: enc->W ; trunk[l]: h->W
+    SubL skipseg;            // enc->W, accumulated into layer skip+1
+    SubL ha, ft;             // h->h_alpha, h->feature
+    SubL vf, vd;             // feature->W/2, gamma(dir)->W/2 (same accumulator)
+    SubL hr;                 // v->h_rgb
+    SubL fr, fa;             // h_rgb->theta_rgb(96), h_alpha->theta_alpha(32)
+    // backward-data (transposed operands): outputs are the INPUT widths
+    SubL bt_fr, bt_fa;       // dtheta_rgb(96)->dh_rgb ; dtheta_alpha(32)->dh_alpha
+    SubL bt_hr;              // dh_rgb->dv
+    SubL bt_vf;              // dv->dfeature
+    SubL bt_ft, bt_ha;       // dfeature->dh ; dh_alpha->dh   (same accumulator)
+    SubL bt_trunk[kMaxDepth];// bt_trunk[l]: dh_l -> dh_{l-1}   (l >= 1; skip layer: h segment only)
+    int32_t D, W, skip, ic, icv, ha_sz, hr_sz, F;
+    uint32_t packed_floats;
+};
+
+// source piece of a packed operand (device-visible POD)
+struct PackDesc {
+    uint32_t src_off;    // flat offset of element [0][col0] of the source matrix (already includes col0)
+    uint32_t src_ld;     // row stride of the source matrix (0 for a bias vector)
+    uint32_t n_rows;     // rows of the source piece  (nn.Linear "out")
+    uint32_t n_cols;     // cols of the source piece  (nn.Linear "in"); 0 => bias vector of n_rows
+    uint32_t dst_off;    // packed offset of the operand (w_off or b_off)
+    uint32_t kc;         // k-chunk count of the destination operand
+    uint32_t out_off;    // offset added to the OUTPUT index inside the operand (concatenated heads)
+    uint32_t red_off;    // offset added to the REDUCTION index inside the operand
+    uint32_t transpose;  // 0: out = row, red = col (forward) ; 1: out = col, red = row (backward-data)
+    uint32_t first_elem; // prefix sum of element counts (for the flat thread -> desc search)
+};
+
+#if defined(__HIPCC__)
+#define CFN_HD __host__ __device__
+#else
+#define CFN_HD
+#endif
+// flat element `local` of piece `d`  ->  (source index in the flat buffer, destination index in the packed buffer)
+CFN_HD inline void pack_map(const PackDesc& d, uint32_t local, uint32_t* src, uint32_t* dst) {
+    if (d.n_cols == 0) {
+        *src = d.src_off + local;
+        *dst = d.dst_off + d.out_off + local;
+        return;
+    }
+    const uint32_t row = local / d.n_cols, col = local - row * d.n_cols;
+    *src = d.src_off + row * d.src_ld + col;
+    const uint32_t o = (d.transpose ? col : row) + d.out_off;
+    const uint32_t r = (d.transpose ? row : col) + d.red_off;
+    const uint32_t nt = o >> 5, lane = (o & 31) + 32 * ((r & 7) >> 2), kc = r >> 3, c = r & 3;
+    *dst = d.dst_off + ((nt * d.kc + kc) * 64 + lane) * 4 + c;
+}
+
+struct PackPlan {
+    NetTab tab;
+    std::vector<PackDesc> descs;
+    uint32_t total_elems = 0;
+};
+
+inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
+    PackPlan P;
+    NetTab& T = P.tab;
+    std::memset(&T, 0, sizeof(T));
+    const int W = c.netwidth, D = c.netdepth, ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), F = c.n_flows;
+    T.D = D; T.W = W; T.skip = D / 2; T.ic = ic; T.icv = icv; T.ha_sz = c.h_alpha_size; T.hr_sz = c.h_rgb_size; T.F = F;
+    uint32_t cur = 0;
+    auto alloc_op = [&](int n_out, int k_red, bool bias) {
+        SubL s;
+        s.nt = (uint16_t)(pad_to(n_out, 32) / 32);
+        s.kc = (uint16_t)(pad_to(k_red, 8) / 8);
+        s.w_off = cur; cur += (uint32_t)s.nt * s.kc * 256;
+        if (bias) { s.b_off = cur; cur += (uint32_t)s.nt * 32; } else s.b_off = 0xffffffffu;
+        return s;
+    };
+    auto piece = [&](const SubL& s, const char* key, int col0, int ncols, int out_off, int red_off, bool transpose) {
+        const ParamEntry* e = L.find(key);
+        PackDesc d{};
+        d.src_off = (uint32_t)(e->off + col0); d.src_ld = (uint32_t)e->cols; d.n_rows = (uint32_t)e->rows;
+        d.n_cols = (uint32_t)ncols; d.dst_off = s.w_off; d.kc = s.kc; d.out_off = out_off; d.red_off = red_off;
+        d.transpose = transpose ? 1 : 0; d.first_elem = P.total_elems;
+        P.total_elems += d.n_rows * d.n_cols;
+        P.descs.push_back(d);
+    };
+    auto bias_piece = [&](const SubL& s, const char* key, int out_off) {
+        const ParamEntry* e = L.find(key);
+        PackDesc d{};
+        d.src_off = (uint32_t)e->off; d.src_ld = 0; d.n_rows = (uint32_t)e->rows; d.n_cols = 0;
+        d.dst_off = s.b_off; d.kc = 0; d.out_off = out_off; d.red_off = 0; d.transpose = 0; d.first_elem = P.total_elems;
+        P.total_elems += d.n_rows;
+        P.descs.push_back(d);
+    };
+    char kw[64], kb[64];
+    // ---- forward operands
+    for (int l = 0; l < D; ++l) {
+        std::snprintf(kw, sizeof kw, "pts_linears.%d.weight", l);
+        std::snprintf(kb, sizeof kb, "pts_linears.%d.bias", l);
+        if (l == 0) {
+            T.trunk[0] = alloc_op(W, ic, true);
+            piece(T.trunk[0], kw, 0, ic, 0, 0, false);
+        } else if (l - 1 == T.skip) {                       // input = [gamma(p) ic | h W]  (MOD:172)
+            T.trunk[l] = alloc_op(W, W, true);
+            piece(T.trunk[l], kw, ic, W, 0, 0, false);
+            T.skipseg = alloc_op(W, ic, false);
+            piece(T.skipseg, kw, 0, ic, 0, 0, false);
+        } else {
+            T.trunk[l] = alloc_op(W, W, true);
+            piece(T.trunk[l], kw, 0, W, 0, 0, false);
+        }
+        bias_piece(T.trunk[l], kb, 0);
+    }
+    T.ha = alloc_op(c.h_alpha_size, W, true);
+    piece(T.ha, "h_alpha_linear.weight", 0, W, 0, 0, false); bias_piece(T.ha, "h_alpha_linear.bias", 0);
+    T.ft = alloc_op(W, W, true);
+    piece(T.ft, "feature_linear.weight", 0, W, 0, 0, false); bias_piece(T.ft, "feature_linear.bias", 0);
+    T.vf = alloc_op(W / 2, W, true);                        // input = [feature W | gamma(d) icv] (MOD:177)
+    piece(T.vf, "views_linears.0.weight", 0, W, 0, 0, false); bias_piece(T.vf, "views_linears.0.bias", 0);
+    T.vd = alloc_op(W / 2, icv, false);
+    piece(T.vd, "views_linears.0.weight", W, icv, 0, 0, false);
+    T.hr = alloc_op(c.h_rgb_size, W / 2, true);
+    piece(T.hr, "h_rgb_linear.weight", 0, W / 2, 0, 0, false); bias_piece(T.hr, "h_rgb_linear.bias", 0);
+    T.fr = alloc_op(kThetaRgb, c.h_rgb_size, true);
+    {
+        const char* ks[4] = {"flows_rgb.amor_d", "flows_rgb.amor_diag1.0", "flows_rgb.amor_diag2.0", "flows_rgb.amor_b"};
+        const int offs[4] = {0, 9 * F, 12 * F, 15 * F};
+        for (int i = 0; i < 4; ++i) {
+            std::snprintf(kw, sizeof kw, "%s.weight", ks[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks[i]);
+            piece(T.fr, kw, 0, c.h_rgb_size, offs[i], 0, false); bias_piece(T.fr, kb, offs[i]);
+        }
+    }
+    T.fa = alloc_op(kThetaAll - kThetaRgb, c.h_alpha_size, true);
+    {
+        const char* ks[3] = {"flows_alpha.amor_diag1.0", "flows_alpha.amor_diag2.0", "flows_alpha.amor_b"};
+        for (int i = 0; i < 3; ++i) {
+            std::snprintf(kw, sizeof kw, "%s.weight", ks[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks[i]);
+            piece(T.fa, kw, 0, c.h_alpha_size, i * F, 0, false); bias_piece(T.fa, kb, i * F);
+        }
+    }
+    // ---- backward-data operands: dX[., in] = sum_out dY[., out] * W[out][in]  -> out index = col, red index = row
+    T.bt_fr = alloc_op(c.h_rgb_size, kThetaRgb, false);
+    {
+        const char* ks[4] = {"flows_rgb.amor_d.weight", "flows_rgb.amor_diag1.0.weight", "flows_rgb.amor_diag2.0.weight", "flows_rgb.amor_b.weight"};
+        const int offs[4] = {0, 9 * F, 12 * F, 15 * F};
+        for (int i = 0; i < 4; ++i) piece(T.bt_fr, ks[i], 0, c.h_rgb_size, 0, offs[i], true);
+    }
+    T.bt_fa = alloc_op(c.h_alpha_size, kThetaAll - kThetaRgb, false);
+    {
+        const char* ks[3] = {"flows_alpha.amor_diag1.0.weight", "flows_alpha.amor_diag2.0.weight", "flows_alpha.amor_b.weight"};
+        for (int i = 0; i < 3; ++i) piece(T.bt_fa, ks[i], 0, c.h_alpha_size, 0, i * F, true);
+    }
+    T.bt_hr = alloc_op(W / 2, c.h_rgb_size, false);
+    piece(T.bt_hr, "h_rgb_linear.weight", 0, W / 2, 0, 0, true);
+    T.bt_vf = alloc_op(W, W / 2, false);
+    piece(T.bt_vf, "views_linears.0.weight", 0, W, 0, 0, true);
+    T.bt_ft = alloc_op(W, W, false);
+    piece(T.bt_ft, "feature_linear.weight", 0, W, 0, 0, true);
+    T.bt_ha = alloc_op(W, c.h_alpha_size, false);
+    piece(T.bt_ha, "h_alpha_linear.weight", 0, W, 0, 0, true);
+    for (int l = 1; l < D; ++l) {
+        std::snprintf(kw, sizeof kw, "pts_linears.%d.weight", l);
+        T.bt_trunk[l] = alloc_op(W, W, false);
+        piece(T.bt_trunk[l], kw, (l - 1 == T.skip) ? ic : 0, W, 0, 0, true);
+    }
+    T.packed_floats = cur;
+    return P;
+}
+
+}  // namespace cfnerf

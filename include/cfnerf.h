@@ -1,0 +1,152 @@
+/*
+ * cfnerf.h - C ABI of the MI355X-native CF-NeRF ray-batch hot path (libcfnerf_hip.so).
+ *
+ * The reference (poetrywanderer/CF-NeRF) is pure Python/PyTorch and has NO FFI layer: its seam is
+ * the Python call chain  render() -> render_rays() -> network_query_fn() -> NeRF_Flows.forward()
+ * -> raw2outputs()  (run_nerf_uncertainty_NF.py:103-170, 457-553, 67-85, 411-454;
+ * model/models.py:188-291).  Each entry point below names the reference function it replaces.
+ * The Python host mirror (cf-nerf_amd/) binds these symbols with ctypes and re-exposes the
+ * reference's signatures; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer; the library allocates only inside cfnerf_model (packed weight
+ *     copies, activation stash, split-K partials) and frees them in cfnerf_model_destroy;
+ *   - every launch is asynchronous on the hipStream_t passed in (pass torch's current stream);
+ *     nothing synchronises the host except cfnerf_model_create/destroy and workspace growth;
+ *   - return value: 0 = OK, negative = cfnerf_status; cfnerf_last_error() gives a thread-local
+ *     message.  No C++ exception crosses the ABI;
+ *   - all arithmetic is fp32 (exact-fp32 MFMA v_mfma_f32_32x32x2_f32 for the dense layers).
+ */
+#ifndef CFNERF_H
+#define CFNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cfnerf_stream;            /* hipStream_t */
+
+typedef enum cfnerf_status {
+    CFNERF_OK = 0,
+    CFNERF_E_INVALID = -1,              /* bad argument / shape */
+    CFNERF_E_UNSUPPORTED = -2,          /* configuration the reference accepts silently but this path rejects */
+    CFNERF_E_HIP = -3,                  /* HIP runtime error (message holds hipGetErrorString) */
+    CFNERF_E_NOMEM = -4
+} cfnerf_status;
+
+/* The flags of config_parser() that reach the hot path (run_nerf_uncertainty_NF.py:556-719). */
+typedef struct cfnerf_cfg {
+    int32_t netdepth;                   /* --netdepth   (8)   skip connection after layer netdepth/2 (RUN:327) */
+    int32_t netwidth;                   /* --netwidth   (256) one of 64, 128, 256, 512 */
+    int32_t multires;                   /* --multires   (10)  -> 63 input channels (run_nerf_helpers.py:54-69) */
+    int32_t multires_views;             /* --multires_views (4) -> 27 channels */
+    int32_t h_alpha_size;               /* --h_alpha_size (32) multiple of 8, <= 64 */
+    int32_t h_rgb_size;                 /* --h_rgb_size (64)  multiple of 8, <= 64 */
+    int32_t n_flows;                    /* --n_flows    (4)   only 4 is built */
+} cfnerf_cfg;
+
+typedef struct cfnerf_model cfnerf_model;   /* opaque: packed weights + workspaces for ONE device */
+
+/* flags for the render / network entry points */
+enum {
+    CFNERF_F_TRAIN      = 1 << 0,       /* train branch of NeRF_Flows.forward (MOD:225-291): log-dets + entropy */
+    CFNERF_F_LINDISP    = 1 << 1,       /* render_rays(lindisp=True)  RUN:513-514 */
+    CFNERF_F_WHITE_BKGD = 1 << 2,       /* raw2outputs(white_bkgd=True) RUN:451-452 */
+    CFNERF_F_STASH      = 1 << 3        /* keep activations for cfnerf_render_bwd (implies TRAIN) */
+};
+
+int         cfnerf_version(void);
+const char* cfnerf_last_error(void);
+
+/* ---- parameters ------------------------------------------------------------------------------
+ * Parameters live in ONE flat fp32 device buffer owned by the caller, laid out in the order of
+ * NeRF_Flows.state_dict() (model/models.py:38-67, 339-350), each tensor
+ * row-major as nn.Linear stores it ([out, in]).  cfnerf_param_count / cfnerf_param_offset describe
+ * that layout so the host side can map state_dict keys to slices of the buffer.  The same layout
+ * is used for gradients and Adam moments, so the multi-GPU exchange is a single all-reduce.      */
+int64_t cfnerf_param_count(const cfnerf_cfg* cfg);
+/* offset (in floats) and element count of a state_dict key such as "pts_linears.5.weight"; -1 if unknown */
+int64_t cfnerf_param_offset(const cfnerf_cfg* cfg, const char* key, int64_t* numel);
+/* i-th key of the layout (0 <= i < number of tensors), NULL past the end */
+const char* cfnerf_param_key(const cfnerf_cfg* cfg, int index);
+
+/* replaces: create_nerf()'s NeRF_Flows(args) construction, RUN:317-331 (device side only) */
+int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out);
+int cfnerf_model_destroy(cfnerf_model* m);
+/* (Re)pack the flat parameter buffer into the MFMA-fragment-ordered copies the kernels stream.
+ * Call after loading a checkpoint and after every optimiser step.  replaces: the implicit
+ * parameter broadcast of nn.DataParallel, RUN:330 */
+int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s);
+
+/* ---- ray set-up ------------------------------------------------------------------------------
+ * replaces: the ray preparation inside render(), RUN:129-158, with get_rays (HLP:288-297) and
+ * ndc_rays (HLP:360-377).  Either `rays_o`/`rays_d` ([N,3] each) are given, or (c2w_host != NULL)
+ * rays are generated for the full H x W image (N must equal H*W).  Output `rays` is the [N,11]
+ * pack o3,d3,near,far,viewdir3 of RUN:152-158.                                                   */
+int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] row-major or NULL*/,
+                      const float* rays_o, const float* rays_d, int64_t N,
+                      int ndc, float near_, float far_, float* rays /*[N,11]*/, cfnerf_stream s);
+
+/* ---- fused forward ---------------------------------------------------------------------------
+ * replaces: render_rays() RUN:457-553 = sampling RUN:510-534, run_network RUN:67-85 with the
+ * positional encoding HLP:21-69, NeRF_Flows.forward MOD:188-291 (TriangularSylvesterNeRF
+ * MOD:358-416, FLW:189-268) and raw2outputs RUN:411-454, in one launch.
+ *   rays    [N,11]          t_vals [S]            t_rand [N,S] or NULL (perturb == 0)
+ *   eps     [K,4] = (eps_rgb0, eps_rgb1, eps_rgb2, eps_alpha) per latent sample (MOD:234,246 / 198,204)
+ *   rgb_map [N,3,K]  disp_map [N,K]  depth_map [N,K]           (always written)
+ *   raw_opt [N,S,K,4], weights_opt [N,S,K], pts_opt [N,S,3]    (NULL = not wanted)
+ *   entropy_out [1]  loss_entropy of MOD:286 (TRAIN only, may be NULL otherwise)                 */
+int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand,
+                      const float* eps, int64_t N, int S, int K, int flags,
+                      float* rgb_map, float* disp_map, float* depth_map,
+                      float* raw_opt, float* weights_opt, float* pts_opt, float* entropy_out,
+                      cfnerf_stream s);
+
+/* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]
+ * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].                   */
+int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags,
+                       float* raw, float* entropy_out, cfnerf_stream s);
+
+/* replaces: raw2outputs() RUN:411-454 as a standalone call.  raw [N,S,K,4], z_vals [N,S], rays_d [N,3] */
+int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d,
+                         int64_t N, int S, int K, int white_bkgd,
+                         float* rgb_map, float* disp_map, float* depth_map, float* weights_opt,
+                         cfnerf_stream s);
+
+/* ---- train step ------------------------------------------------------------------------------
+ * replaces: the loss lines RUN:1026-1050 (K-mean MSE/PSNR, KDE negative log-likelihood with the
+ * detached n/(n-1)-scaled bandwidth, + beta1 * entropy).  Writes d(loss)/d(rgb_map) [N,3,K] and
+ * scalars_out[4] = {loss, loss_nll, mse, psnr}.  `n_total` is the GLOBAL ray count the means are
+ * taken over (N for one GPU, N * world_size when rays are sharded).                              */
+int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K,
+                        float beta1, int64_t n_total, float* d_rgb_map, float* scalars_out, cfnerf_stream s);
+
+/* replaces: loss.backward() (RUN:1066) through raw2outputs, the flows and the MLP for the batch
+ * of the last cfnerf_render_fwd(... CFNERF_F_STASH ...) on this model.  d_depth_map may be NULL.
+ * d_entropy points to ONE device float, d(loss)/d(loss_entropy) (e.g. beta1); NULL means 0.
+ * grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.        */
+int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_depth_map, const float* d_entropy,
+                      float* grad_flat, cfnerf_stream s);
+
+/* replaces: torch.optim.Adam.step() RUN:339,1067 on the flat buffers (betas .9/.999, eps 1e-8),
+ * followed by the re-pack of cfnerf_model_set_params.  step is 1-based.  grad_scale multiplies
+ * the gradient first (1/world_size after a sum all-reduce).                                      */
+int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat, float* exp_avg,
+                     float* exp_avg_sq, int64_t step, float lr, float grad_scale, cfnerf_stream s);
+
+/* bytes currently held by the model's stash / workspaces (diagnostics) */
+int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
+
+/* seconds^-3 helper for bench.py: average duration (ms) of the last `n` fused-forward launches
+ * measured with HIP events on the launch stream; returns <0 if timing was not enabled.           */
+int   cfnerf_timing_enable(cfnerf_model* m, int enable);
+float cfnerf_timing_last_ms(cfnerf_model* m, int which /*0=fwd 1=bwd_tail 2=bwd_data 3=bwd_dw 4=adam*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFNERF_H */

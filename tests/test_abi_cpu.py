@@ -1,0 +1,136 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/cfnerf.h declares,
+its flat parameter layout is the reference's state_dict order, and the packed (MFMA-fragment-ordered)
+operands decode back to the right matrices.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cfnerf_amd
+from cfnerf_amd import _lib as L
+from oracle import cfnerf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cfnerf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cfnerf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert L.lib().cfnerf_version() >= 100
+
+
+@pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64)])
+def test_flat_layout_is_state_dict_order(W, ha, hr):
+    cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
+    lay, total = cfnerf_amd.param_layout(cfg)
+    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr)
+    shapes = O.param_shapes(ocfg)
+    assert list(lay.keys()) == list(shapes.keys())
+    off = 0
+    for k, shp in shapes.items():
+        assert lay[k] == (off, int(np.prod(shp))), k
+        off += int(np.prod(shp))
+    assert total == off
+    if W == 256:
+        assert total == 617410
+
+
+def test_unsupported_configs_are_rejected_loudly():
+    lib = L.lib()
+    for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 3), L.Cfg(8, 256, 11, 4, 32, 64, 4),
+                L.Cfg(1, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 30, 64, 4)):
+        assert lib.cfnerf_param_count(C.byref(bad)) < 0
+        assert lib.cfnerf_last_error() != b""
+
+
+def _decode(packed, w_off, kc, nt):
+    """packed operand -> dense [nt*32, kc*8] matrix (inverse of the fragment order in cfnerf_layout.h)."""
+    blk = packed[w_off:w_off + nt * kc * 256].reshape(nt, kc, 64, 4)
+    M = np.zeros((nt * 32, kc * 8), np.float32)
+    for lane in range(64):
+        rows = np.arange(nt) * 32 + (lane & 31)
+        for c in range(4):
+            cols = np.arange(kc) * 8 + 4 * (lane >> 5) + c
+            M[np.ix_(rows, cols)] = blk[:, :, lane, c]
+    return M
+
+
+@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 48)])
+def test_packed_operands_decode_to_the_weights(W, ha, hr):
+    lib = C.CDLL(L.LIB_PATH)
+    cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
+    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr)
+    p = {k: v.numpy() for k, v in O.make_params(ocfg, 5).items()}
+    flat = np.concatenate([p[k].reshape(-1) for k in O.param_shapes(ocfg)]).astype(np.float32)
+    lib.cfnerf_debug_packed_floats.restype = C.c_int64
+    n = lib.cfnerf_debug_packed_floats(C.byref(cfg))
+    packed = np.zeros(n, np.float32)
+    rc = lib.cfnerf_debug_pack_host(C.byref(cfg), flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+    def op(name, idx=0):
+        out = (C.c_uint32 * 4)()
+        assert lib.cfnerf_debug_operand(C.byref(cfg), name.encode(), idx, out) == 0
+        w_off, b_off, kc, nt = [int(v) for v in out]
+        M = _decode(packed, w_off, kc, nt)
+        b = packed[b_off:b_off + nt * 32] if b_off != 0xffffffff else None
+        return M, b
+
+    def expect(M, ref, what):
+        r, c = ref.shape
+        assert np.array_equal(M[:r, :c], ref), what
+        Z = M.copy()
+        Z[:r, :c] = 0
+        assert not Z.any(), what + " padding must be zero"
+
+    ic = 63
+    for l in range(8):
+        Wl, bl = p[f"pts_linears.{l}.weight"], p[f"pts_linears.{l}.bias"]
+        M, b = op("trunk", l)
+        if l == 5:
+            expect(M, Wl[:, ic:], "trunk5 h segment")
+            Ms, _ = op("skipseg")
+            expect(Ms, Wl[:, :ic], "trunk5 enc segment")
+        else:
+            expect(M, Wl, f"trunk{l}")
+        assert np.array_equal(b[:W], bl)
+    M, b = op("ha"); expect(M, p["h_alpha_linear.weight"], "ha"); assert np.array_equal(b[:ha], p["h_alpha_linear.bias"])
+    M, b = op("ft"); expect(M, p["feature_linear.weight"], "ft")
+    Vw = p["views_linears.0.weight"]
+    M, b = op("vf"); expect(M, Vw[:, :W], "vf"); assert np.array_equal(b[:W // 2], p["views_linears.0.bias"])
+    M, _ = op("vd"); expect(M, Vw[:, W:], "vd")
+    M, b = op("hr"); expect(M, p["h_rgb_linear.weight"], "hr")
+    fr = np.concatenate([p["flows_rgb.amor_d.weight"], p["flows_rgb.amor_diag1.0.weight"],
+                         p["flows_rgb.amor_diag2.0.weight"], p["flows_rgb.amor_b.weight"]], 0)
+    frb = np.concatenate([p["flows_rgb.amor_d.bias"], p["flows_rgb.amor_diag1.0.bias"],
+                          p["flows_rgb.amor_diag2.0.bias"], p["flows_rgb.amor_b.bias"]], 0)
+    M, b = op("fr"); expect(M, fr, "fr"); assert np.array_equal(b[:72], frb) and not b[72:].any()
+    fa = np.concatenate([p["flows_alpha.amor_diag1.0.weight"], p["flows_alpha.amor_diag2.0.weight"],
+                         p["flows_alpha.amor_b.weight"]], 0)
+    M, b = op("fa"); expect(M, fa, "fa")
+    # backward-data operands are the transposes
+    M, _ = op("bt_fr"); expect(M, fr.T, "bt_fr")
+    M, _ = op("bt_fa"); expect(M, fa.T, "bt_fa")
+    M, _ = op("bt_hr"); expect(M, p["h_rgb_linear.weight"].T, "bt_hr")
+    M, _ = op("bt_vf"); expect(M, Vw[:, :W].T, "bt_vf")
+    M, _ = op("bt_ft"); expect(M, p["feature_linear.weight"].T, "bt_ft")
+    M, _ = op("bt_ha"); expect(M, p["h_alpha_linear.weight"].T, "bt_ha")
+    for l in range(1, 8):
+        Wl = p[f"pts_linears.{l}.weight"]
+        M, _ = op("bt_trunk", l)
+        expect(M, (Wl[:, ic:] if l == 5 else Wl).T, f"bt_trunk{l}")
+
+
+def test_host_mirror_rejects_cpu_tensors_and_dead_flags():
+    import torch
+    with pytest.raises(RuntimeError, match="GPU"):
+        cfnerf_amd.raw2outputs(torch.zeros(2, 4, 1, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    with pytest.raises(ValueError, match="use_viewdirs"):
+        cfnerf_amd.render(4, 4, 1.0, rays=(torch.zeros(1, 3), torch.zeros(1, 3)), use_viewdirs=False)

@@ -1,0 +1,247 @@
+"""-m gpu: the HIP path (through the C ABI and the reference-shaped Python mirror) against
+(1) golden vectors captured from the real reference and (2) the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import cfnerf_amd
+from oracle import cfnerf_oracle as O
+from util_hip import ATOL, ATOL_DISP, RTOL, build_model, close, fern_rays
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.tensor(np.asarray(a))
+DEV = "cuda"
+
+
+def cfg_from(g):
+    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]),
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
+
+
+def test_native_library_is_loaded():
+    from cfnerf_amd import _lib
+    assert _lib.lib().cfnerf_version() >= 100
+    with open("/proc/self/maps") as f:
+        assert "libcfnerf_hip.so" in f.read()
+
+
+# ---------------------------------------------------------------- NeRF_Flows.forward (MOD:188-291)
+@pytest.mark.parametrize("tag", ["w64", "w256", "w64k1", "w128k5"])
+def test_model_forward_vs_reference_golden(golden, tag):
+    g = golden(f"g123_model_{tag}")
+    cfg = cfg_from(g)
+    _, kw, _, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    x = T(g["x90"]).to(DEV)
+    net.sample_alpha = T(g["eps_alpha"]).clone()          # R9: eval latents are plain attributes
+    net.sample_rgb = T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        raw_e, aux = net(x, False, True)
+        raw_t, ent = net(x, False, False, eps_alpha=T(g["eps_alpha"]), eps_rgb=T(g["eps_rgb"]))
+    close(raw_e, g["raw_eval"], what="raw_eval")
+    assert float(aux.abs().max()) == 0.0 and aux.shape == raw_e.shape
+    close(raw_t, g["raw_train"], what="raw_train")
+    assert list(ent.shape) == list(g["loss_entropy_shape"])
+    close(ent.reshape(-1)[0], g["loss_entropy"], what="loss_entropy")
+
+
+@pytest.mark.parametrize("W,K,P", [(256, 4, 1000), (256, 32, 129), (512, 8, 200), (128, 3, 64), (64, 1, 1)])
+def test_model_forward_vs_oracle(W, K, P):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
+    _, kw, _, model, p, _ = build_model(cfg, 100 + W + K)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(P, 90, generator=g) * 2 - 1
+    ea, er = torch.randn(K, 1, generator=g), torch.randn(K, 3, generator=g)
+    with torch.no_grad():
+        raw_t, ent = model.module(x.to(DEV), False, False, eps_alpha=ea, eps_rgb=er)
+    raw_o, ent_o = O.nerf_flows_forward(p, x, ea, er, cfg, is_test=False)
+    close(raw_t, raw_o, what="raw")
+    close(ent.reshape(-1)[0], ent_o, what="entropy")
+
+
+# ---------------------------------------------------------------- raw2outputs (RUN:411-454)
+@pytest.mark.parametrize("wb", [False, True])
+def test_composite_vs_reference_golden(golden, wb):
+    g = golden("g4_composite")
+    s = "wb" if wb else "nb"
+    rgb, disp, w, depth = cfnerf_amd.raw2outputs(T(g["raw"]).to(DEV), T(g["z_vals"]).to(DEV), T(g["rays_d"]).to(DEV), 0, wb)
+    close(rgb, g[f"rgb_map_{s}"], what="rgb_map")
+    close(w, g[f"weights_{s}"], what="weights")
+    close(depth, g[f"depth_{s}"], what="depth")
+    close(disp, g[f"disp_{s}"], atol=ATOL_DISP, rtol=1e-3, what="disp")
+
+
+@pytest.mark.parametrize("N,S,K", [(5, 128, 4), (3, 70, 3), (2, 1, 1), (7, 200, 32), (1, 64, 5)])
+def test_composite_vs_oracle_ragged(N, S, K):
+    g = torch.Generator().manual_seed(N * 1000 + S + K)
+    raw = torch.randn(N, S, K, 4, generator=g) * 3
+    z = torch.sort(torch.rand(N, S, generator=g) * 4 + 0.5, -1).values
+    d = torch.randn(N, 3, generator=g)
+    for wb in (False, True):
+        rgb, disp, w, depth = cfnerf_amd.raw2outputs(raw.to(DEV), z.to(DEV), d.to(DEV), 0, wb)
+        rgb_o, disp_o, w_o, depth_o = O.raw2outputs(raw, z, d, wb)
+        close(rgb, rgb_o, what="rgb")
+        close(w, w_o, what="weights")
+        close(depth, depth_o, what="depth")
+        close(disp, disp_o, atol=ATOL_DISP, rtol=1e-3, what="disp")
+
+
+# ---------------------------------------------------------------- render (RUN:103-170) on a ray batch
+@pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
+def test_render_batch_vs_reference_golden(golden, tag):
+    g = golden(f"g57_render_{tag}")
+    cfg = cfg_from(g)
+    over = dict(no_ndc=not bool(g["ndc"]), lindisp=bool(g["lindisp"]), white_bkgd=bool(g["white_bkgd"]))
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]), **over)
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    rays = T(g["rays"]).to(DEV)
+    near, far = float(g["near"]), float(g["far"])
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(H, W, focal, chunk=8192, rays=rays, near=near, far=far,
+                                                      verbose=False, retraw=False, t_rand=T(g["t_rand"]),
+                                                      eps_alpha=T(g["eps_alpha"]), eps_rgb=T(g["eps_rgb"]), **kw_train)
+    assert sorted(extras.keys()) == list(g["train_extras_keys"])
+    close(extras["pts"], g["pts"], atol=1e-6, rtol=1e-6, what="pts")
+    close(extras["raw"], g["raw"], what="raw")
+    close(rgbs, g["rgb_map"], what="rgb_map")
+    close(depth, g["depth_map"], what="depth_map")
+    close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    assert extras["loss_entropy"].numel() == int(g["loss_entropy_numel"])
+    close(extras["loss_entropy"].mean(), g["loss_entropy"], what="loss_entropy")
+    # eval branch: fixed latents, last = 0, perturb off (RUN:403-407)
+    net.sample_alpha = T(g["eps_alpha"]).clone()
+    net.sample_rgb = T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, extras_e = cfnerf_amd.render(H, W, focal, chunk=8192, rays=rays, near=near, far=far, **kw_test)
+    assert sorted(extras_e.keys()) == list(g["eval_extras_keys"])
+    close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth_e, g["depth_map_eval"], what="depth_map_eval")
+    close(disp_e, g["disp_map_eval"], atol=ATOL_DISP, rtol=1e-3, what="disp_map_eval")
+
+
+def test_render_c2w_vs_reference_golden(golden):
+    g = golden("g6_render_c2w")
+    cfg = cfg_from(g)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    net.sample_alpha = T(g["eps_alpha"]).clone()
+    net.sample_rgb = T(g["eps_rgb"]).clone()
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    with torch.no_grad():
+        rgbs, disp, depth, _ = cfnerf_amd.render(H, W, focal, chunk=8192, c2w=T(g["c2w"]), near=0., far=1., **kw_test)
+    assert list(rgbs.shape) == [H, W, 3, 4] and list(disp.shape) == [H, W, 4]
+    close(rgbs, g["rgb_map"], what="rgb_map")
+    close(depth, g["depth_map"], what="depth_map")
+    close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+
+
+@pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True)])
+def test_render_vs_oracle(W, K, N, ndc):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, 300 + W + K, no_ndc=not ndc)
+    rng = np.random.default_rng(W + K + N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    near, far = (0., 1.) if ndc else (1.2, 8.0)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), near=near, far=far, t_rand=t_rand,
+                                                      eps_alpha=ea, eps_rgb=er, **kw_train)
+    r = O.render(p, H, Wd, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), ndc=ndc, near=near, far=far, t_rand=t_rand)
+    close(extras["raw"], r["raw"], what="raw")
+    close(rgbs, r["rgb_map"], what="rgb_map")
+    close(depth, r["depth_map"], what="depth_map")
+    close(disp, r["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    close(extras["loss_entropy"].mean(), r["loss_entropy"], what="entropy")
+
+
+def test_ragged_sample_table():
+    """S not a multiple of the 64-row tile, S < 64, and a custom t_vals table (the kernel takes it as input)."""
+    cfg = O.OracleCfg(netwidth=64, K_samples=3)
+    _, kw_train, _, model, p, _ = build_model(cfg, 41)
+    rng = np.random.default_rng(5)
+    for S in (70, 17, 129):
+        N = 9
+        rays, (H, Wd, focal) = fern_rays(rng, N)
+        tv = torch.sort(torch.tensor(rng.uniform(0, 1, S), dtype=torch.float32)).values
+        t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32)
+        ea = torch.tensor(rng.standard_normal((3, 1)), dtype=torch.float32)
+        er = torch.tensor(rng.standard_normal((3, 3)), dtype=torch.float32)
+        packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+        kw = dict(kw_train)
+        kw.pop("use_viewdirs"); kw["N_samples"] = S
+        with torch.no_grad():
+            ret = cfnerf_amd.render_rays(packed.to(DEV), t_vals=tv, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, retweights=True, **kw)
+        r = O.render_rays(p, packed, cfg, ea, er, True, t_rand=t_rand, t_vals=tv)
+        close(ret["raw"], r["raw"], what=f"raw S={S}")
+        close(ret["rgb_map"], r["rgb_map"], what=f"rgb S={S}")
+        close(ret["weights"], r["weights"], what=f"weights S={S}")
+        close(ret["depth_map"], r["depth_map"], what=f"depth S={S}")
+
+
+def test_unfused_query_path_matches_fused():
+    """A caller-supplied network_query_fn (run_network -> NeRF_Flows kernel -> composite kernel) vs the fused launch."""
+    cfg = O.OracleCfg(netwidth=256, K_samples=4)
+    args, kw_train, kw_test, model, p, _ = build_model(cfg, 77)
+    rng = np.random.default_rng(3)
+    rays, (H, Wd, focal) = fern_rays(rng, 50)
+    t_rand = torch.tensor(rng.uniform(0, 1, (50, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((4, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((4, 3)), dtype=torch.float32)
+    fused_q = kw_train["network_query_fn"]
+    custom = lambda *a, **k: fused_q(*a, **k)          # same query, but not marked fusable
+    with torch.no_grad():
+        a = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+        kw2 = dict(kw_train, network_query_fn=custom)
+        b = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw2)
+    close(b[3]["raw"], a[3]["raw"], what="raw")
+    close(b[0], a[0], what="rgb_map")
+    close(b[2], a[2], what="depth")
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+def test_full_size_properties_config2():
+    """BASELINE config 2 sizes (N_rand 1024, S 128, K 4, W 256): properties that need no oracle run."""
+    cfg = O.OracleCfg(netwidth=256, K_samples=4)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, 9)
+    rng = np.random.default_rng(11)
+    N = 1024
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    rays = rays.to(DEV)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((4, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((4, 3)), dtype=torch.float32)
+    kw = dict(t_rand=t_rand, eps_alpha=ea, eps_rgb=er)
+    with torch.no_grad():
+        full = cfnerf_amd.render(H, Wd, focal, rays=rays, **kw, **kw_train)
+        # (1) rays are independent: two half batches reproduce the full batch bit-for-bit
+        h0 = cfnerf_amd.render(H, Wd, focal, rays=rays[:, :400], t_rand=t_rand[:400], eps_alpha=ea, eps_rgb=er, **kw_train)
+        h1 = cfnerf_amd.render(H, Wd, focal, rays=rays[:, 400:], t_rand=t_rand[400:], eps_alpha=ea, eps_rgb=er, **kw_train)
+        assert torch.equal(torch.cat([h0[0], h1[0]]), full[0])
+        assert torch.equal(torch.cat([h0[2], h1[2]]), full[2])
+        # (2) latent samples are independent: permuting eps permutes the K axis bit-for-bit
+        perm = torch.tensor([2, 0, 3, 1])
+        pk = cfnerf_amd.render(H, Wd, focal, rays=rays, t_rand=t_rand, eps_alpha=ea[perm], eps_rgb=er[perm], **kw_train)
+        assert torch.equal(pk[0], full[0][..., perm])
+        assert torch.equal(pk[3]["raw"], full[3]["raw"][:, :, perm])
+        # (3) composite invariants: rgb in [0,1], depth within [near, far] of the NDC volume
+        rgb, depth = full[0], full[2]
+        assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5
+        assert float(depth.min()) >= 0.0 and float(depth.max()) <= 1.0 + 1e-5
+    assert torch.isfinite(full[3]["loss_entropy"]).all()
+
+
+def test_empty_batch_and_bad_arguments():
+    cfg = O.OracleCfg(netwidth=64, K_samples=2)
+    _, kw_train, _, model, _, _ = build_model(cfg, 1)
+    kw = {k: v for k, v in kw_train.items() if k != "use_viewdirs"}
+    ret = cfnerf_amd.render_rays(torch.zeros(0, 11, device=DEV), **kw)
+    assert ret["rgb_map"].shape == (0, 3, 2)
+    with pytest.raises(ValueError, match="N_samples"):
+        cfnerf_amd.render_rays(torch.zeros(4, 11, device=DEV), **dict(kw, N_samples=64))
+    with pytest.raises(NotImplementedError):
+        cfnerf_amd.render_rays(torch.zeros(4, 11, device=DEV), **dict(kw, N_importance=64))
+    with pytest.raises(ValueError):
+        model.module(torch.zeros(3, 63, device=DEV), False, True)
