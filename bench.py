@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X-native CF-NeRF ray-batch hot path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic fern-shaped rays at
+BASELINE.json configs[1]: N_rand = 1024 rays per GPU, S = 128 samples (the reference's hard-coded
+table, single pass - it has no fine network), K = 4 latent samples, W = 256, D = 8.
+  --mode train (default when the backward is built): forward + KDE-NLL loss + backward + Adam
+  --mode eval : fused forward render only
+Rays are sharded across ranks (weak scaling: N_rand per GPU is fixed); the only exchange is one
+RCCL all-reduce of the flat gradient per train step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+N_RAND, S, K, W, D = 1024, 128, 4, 256, 8
+
+
+def gemm_flops_per_point(W=256, ha=32, hr=64, ic=63, icv=27, F=4):
+    """Algorithmic MACs per point (deduplicated flow heads) x 2."""
+    macs = ic * W + 3 * W * W + (W + ic) * W + 2 * W * W          # trunk (D = 8: layers 0, 1-4, 5 (skip), 6-7)
+    macs += W * ha + W * W + (W + icv) * (W // 2) + (W // 2) * hr  # h_alpha, feature, views, h_rgb
+    macs += hr * 18 * F + ha * 3 * F                               # live flow-parameter heads
+    return 2 * macs
+
+
+def synth_batch(rank, n, device):
+    from util_hip import fern_rays
+    rng = np.random.default_rng(1000 + rank)
+    rays, (H, Wd, focal) = fern_rays(rng, n)
+    target = torch.tensor(rng.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    return rays.to(device), target.to(device), (H, Wd, focal)
+
+
+def cpu_baseline(mode, budget_s=25.0):
+    """The CPU oracle (op-for-op PyTorch-CPU restatement of the reference, oracle/) timed on this box's
+    host cores on a bounded sample of the same workload.  The thread count is swept (all usable
+    cores is NOT the fastest for these GEMM sizes) and the best setting is reported with its count."""
+    from oracle import cfnerf_oracle as O
+    from util_hip import fern_rays
+    n_rays = 128 if mode == "train" else 256
+    cfg = O.OracleCfg(netwidth=W, K_samples=K)
+    p = O.make_params(cfg, 0)
+    rng = np.random.default_rng(5)
+    rays, (H, Wd, focal) = fern_rays(rng, n_rays)
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    t_rand = torch.rand(n_rays, S)
+    ea, er = torch.randn(K, 1), torch.randn(K, 3)
+    target = torch.rand(n_rays, 3)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+
+    def one():
+        t0 = time.perf_counter()
+        if mode == "train":
+            scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, 0.01)
+            O.adam_step({k: v.clone() for k, v in p.items()}, grads, {}, 1, 5e-4)
+        else:
+            with torch.no_grad():
+                O.render_rays(p, packed, cfg, ea, er, False)
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    best, best_thr, tried = float("inf"), 1, []
+    for thr in sorted({min(usable, t) for t in (8, 16, 32, 64, usable)}):
+        if time.perf_counter() - t_start > budget_s:
+            break
+        torch.set_num_threads(thr)
+        one()                                   # warm-up (thread pool, allocator)
+        dt = min(one(), one())
+        tried.append(thr)
+        if dt < best:
+            best, best_thr = dt, thr
+    return {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
+            "sample": f"{n_rays} rays x {S} samples x K={K}, W={W}: best of 2 {mode} steps of the PyTorch-CPU oracle at "
+                      f"{best_thr} threads (swept {tried} of {usable} usable cores; anomaly detection off)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["train", "eval"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cfnerf_amd
+    from cfnerf_amd import _lib as L
+    from oracle import cfnerf_oracle as O       # only for the deterministic weight generator + cpu_baseline
+    from util_hip import build_model
+    try:
+        from cfnerf_amd import train as T
+        have_train = T.backward_available()
+    except Exception:
+        T, have_train = None, False
+    mode = args.mode or ("train" if have_train else "eval")
+    if mode == "train" and not have_train:
+        raise SystemExit("train mode requested but the backward kernels are not built")
+
+    cfg = O.OracleCfg(netwidth=W, K_samples=K)
+    _, kw_train, kw_test, model, _, _ = build_model(cfg, 0, device=dev)
+    net = model.module
+    rays, target, (H, Wd, focal) = synth_batch(rank, N_RAND, dev)
+    lib = L.lib()
+    lib.cfnerf_timing_enable(net.handle, 1)
+    g = torch.Generator(device=dev).manual_seed(1234)           # same latent samples on every rank
+
+    if mode == "train":
+        trainer = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world)
+
+    def step():
+        t_rand = torch.rand(N_RAND, S, device=dev)
+        eps = torch.randn(K, 4, device=dev, generator=g)
+        if mode == "train":
+            return trainer.step(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps, **kw_train)
+        with torch.no_grad():
+            return cfnerf_amd.render(H, Wd, focal, rays=rays, **kw_test)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event duration of the dominant kernel (fused forward) on the launch stream
+    sync()
+    dt = time.perf_counter() - t0
+    # per-launch duration of the dominant kernel from the library's HIP events (last step; queried after the timed region)
+    fwd_ms = lib.cfnerf_timing_last_ms(net.handle, 0)
+    extra_ms = {}
+    if mode == "train":
+        for name, idx in (("bwd_tail", 1), ("bwd_data", 2), ("bwd_dw", 3), ("adam", 4)):
+            extra_ms[name] = lib.cfnerf_timing_last_ms(net.handle, idx)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        rays_per_s = N_RAND * world * args.steps / dt
+        fl = gemm_flops_per_point(W) * N_RAND * S          # forward GEMM FLOPs of one launch of the fused forward kernel
+        roof = {"bound": "mfma", "kernel": "fused_fwd_kernel<256,rays>", "achieved": fl / (fwd_ms * 1e-3) / 1e12,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": None,
+                "launch_ms": fwd_ms, "flops_per_launch": fl}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        out = {
+            "metric": "rays/sec (train step)" if mode == "train" else "rays/sec (eval render, fused forward)",
+            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"LLFF-fern-shaped synthetic rays, N_rand={N_RAND}/GPU, S={S} (reference table, single pass), "
+                                   f"K={K}, W={W}, D={D}, NDC, mode={mode}",
+                       "parallelism": f"ray-sharded dp{world}" + (", 1 RCCL all-reduce of flat grads/step" if mode == "train" and world > 1 else "")},
+            "roofline": roof,
+        }
+        if extra_ms:
+            out["kernel_ms"] = dict(fwd=fwd_ms, **extra_ms)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mode)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -475,7 +475,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
     if not fused:
         return _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_rand, eps, is_train, lindisp, white_bkgd)
 
-    if is_train and torch.is_grad_enabled() and model.flat.requires_grad:
+    if is_train and N > 0 and torch.is_grad_enabled() and model.flat.requires_grad:
         model._last_shape = (N, 3, K)
         rgb_map, disp, depth, ent, raw, pts = _RenderFn.apply(model.flat, model, rays, t_vals, t_rand, eps, flags, True)
         return {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth, 'raw': raw,

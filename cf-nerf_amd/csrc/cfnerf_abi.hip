@@ -142,9 +142,9 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
                       int64_t N, int S, int K, int flags, float* rgb_map, float* disp_map, float* depth_map,
                       float* raw_opt, float* weights_opt, float* pts_opt, float* entropy_out, cfnerf_stream s) {
     if (int rc = check_common(m, K)) return rc;
-    if (!rays || !t_vals || !eps || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
     if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
-    if (N == 0) return CFNERF_OK;
+    if (N == 0) return CFNERF_OK;            // empty batch: nothing to do (buffers may be NULL)
+    if (!rays || !t_vals || !eps || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
     hipStream_t st = (hipStream_t)s;
     if (flags & CFNERF_F_STASH) flags |= CFNERF_F_TRAIN;
     const bool train = flags & CFNERF_F_TRAIN;
@@ -179,10 +179,10 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
 int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags, float* raw,
                        float* entropy_out, cfnerf_stream s) {
     if (int rc = check_common(m, K)) return rc;
-    if (!x || !eps || !raw) return fail(CFNERF_E_INVALID, "NULL argument");
     if (flags & CFNERF_F_STASH) return fail(CFNERF_E_UNSUPPORTED, "STASH is only available through cfnerf_render_fwd");
     if (P < 0) return fail(CFNERF_E_INVALID, "bad P");
     if (P == 0) return CFNERF_OK;
+    if (!x || !eps || !raw) return fail(CFNERF_E_INVALID, "NULL argument");
     const bool train = flags & CFNERF_F_TRAIN;
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     hipStream_t st = (hipStream_t)s;
@@ -200,9 +200,9 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
 int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K,
                          int white_bkgd, float* rgb_map, float* disp_map, float* depth_map, float* weights_opt,
                          cfnerf_stream s) {
-    if (!raw || !z_vals || !rays_d || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
     if (N < 0 || S < 1 || K < 1) return fail(CFNERF_E_INVALID, "bad N/S/K");
     if (N == 0) return CFNERF_OK;
+    if (!raw || !z_vals || !rays_d || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
     HIPCHK(launch_composite(raw, z_vals, rays_d, N, S, K, white_bkgd, rgb_map, disp_map, depth_map, weights_opt, (hipStream_t)s));
     return CFNERF_OK;
 }

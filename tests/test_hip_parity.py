@@ -71,7 +71,7 @@ def test_composite_vs_reference_golden(golden, wb):
     close(disp, g[f"disp_{s}"], atol=ATOL_DISP, rtol=1e-3, what="disp")
 
 
-@pytest.mark.parametrize("N,S,K", [(5, 128, 4), (3, 70, 3), (2, 1, 1), (7, 200, 32), (1, 64, 5)])
+@pytest.mark.parametrize("N,S,K", [(5, 128, 4), (3, 70, 3), (2, 2, 1), (7, 200, 32), (1, 64, 5)])
 def test_composite_vs_oracle_ragged(N, S, K):
     g = torch.Generator().manual_seed(N * 1000 + S + K)
     raw = torch.randn(N, S, K, 4, generator=g) * 3
