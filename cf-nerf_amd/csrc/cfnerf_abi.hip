@@ -27,6 +27,10 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(CFNERF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+extern "C" void cfnerf_set_error_(const char* msg) {      // used by the other translation units
+    std::snprintf(g_err, sizeof g_err, "%s", msg);
+}
+
 extern "C" {
 
 int cfnerf_version(void) { return 100; }
@@ -103,6 +107,7 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     hipFree(m->d_packed); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
     hipFree(m->d_eps); hipFree(m->d_scratch_ent);
     m->stash.release();
+    m->bwd.release();
     for (void* p : m->owned) hipFree(p);
     for (int i = 0; i < kNumTimers; ++i) { hipEventDestroy(m->ev0[i]); hipEventDestroy(m->ev1[i]); }
     delete m;
@@ -160,7 +165,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         if (int rc = m->stash.ensure(m->cfg, N, S, K)) return fail(rc, "stash allocation failed (%lld points)", (long long)a.P);
         Stash& q = m->stash;
         a.st_enc = q.enc; a.st_gd = q.gd; a.st_h = q.h; a.st_feat = q.feat; a.st_v = q.v; a.st_ha = q.ha; a.st_hr = q.hr;
-        a.st_theta = q.theta; a.st_z = q.z;
+        a.st_theta = q.theta; a.st_z = q.z; a.st_at = q.at;
         if (!a.raw) a.raw = q.raw;
         q.raw_used = a.raw;
         HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -1,0 +1,63 @@
+// cfnerf_bwd.h - argument blocks and per-model plan of the backward pass (internal)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "cfnerf_layout.h"
+
+namespace cfnerf {
+
+struct TailArgs {
+    const float *raw, *theta, *at, *z, *rays, *eps, *flat;
+    const float *d_rgb, *d_depth, *d_ent;
+    int64_t N, P;
+    int32_t S, K, flags;
+    float *g_theta, *gms_partials;
+};
+
+struct BwdArgs {
+    const NetTab* tab;
+    const float* wp;
+    int64_t P;
+    int32_t n_wg, nb;
+    const float* g_theta;                                 // [P,128]   input (from the tail kernel)
+    float *g_hr, *g_ha, *g_v, *g_feat, *g_h;              // outputs: pre-activation gradients, row-major per point
+    const float *st_v, *st_h;                             // stashed activations for the ReLU masks
+    float* dbp;                                           // [n_wg, nb] bias-gradient partials
+    int32_t db_h, db_feat, db_v, db_ha, db_hr, db_theta;  // column offsets inside a dbp row
+};
+
+// one 128 x 256 output tile of a weight-gradient job  dW[n][k] = sum_p dY[p][n] * X[p][k]
+struct DwTile {
+    const float* dY; int32_t ldY, N, Npad;                // Npad: readable width of a dY row from the slice start
+    const float* X;  int32_t ldX, K, Kpad;                // K: columns to store, Kpad: readable width of an X row
+    int32_t n0, k0;
+    int32_t nseg, seg_row[4];                             // destination row segments (concatenated flow heads)
+    uint32_t seg_dst[4];
+    int32_t dst_ld, dst_col;
+};
+
+struct BiasMap { int32_t col0, count; uint32_t dst; };
+
+struct BwdPlan {
+    bool built = false;
+    int nb = 0, db_h = 0, db_feat = 0, db_v = 0, db_ha = 0, db_hr = 0, db_theta = 0;
+    std::vector<BiasMap> bias_maps;
+    BiasMap* d_bias_maps = nullptr;
+    float* d_dbp = nullptr; int dbp_wg = 0;
+    float* d_partials = nullptr; int partials_split = 0;
+    DwTile* d_tiles = nullptr; int n_tiles = 0;
+    const float* tiles_for = nullptr; int64_t tiles_P = 0;
+    void release() {
+        if (d_bias_maps) hipFree(d_bias_maps);
+        if (d_dbp) hipFree(d_dbp);
+        if (d_partials) hipFree(d_partials);
+        if (d_tiles) hipFree(d_tiles);
+        d_bias_maps = nullptr; d_dbp = nullptr; d_partials = nullptr; d_tiles = nullptr;
+        dbp_wg = partials_split = n_tiles = 0; tiles_for = nullptr; tiles_P = 0;
+    }
+};
+
+}  // namespace cfnerf

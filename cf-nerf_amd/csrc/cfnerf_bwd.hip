@@ -1,9 +1,759 @@
-// cfnerf_bwd.hip - loss, backward and optimiser kernels (placeholder until the backward lands)
+// cfnerf_bwd.hip - train-step kernels for gfx950: KDE-NLL loss, adjoint of composite + flows ("tail"),
+// fused backward-data MLP kernel, split-K weight-gradient GEMM, gradient reduce, fused Adam.
+//
+// Reference lines replaced: loss RUN:1026-1050; loss.backward() RUN:1066 (autograd of RUN:411-454,
+// MOD:188-291, FLW:225-268); Adam RUN:339,1067.
+//
+// Data flow of cfnerf_render_bwd (activations come from the CFNERF_F_STASH forward):
+//   tail_bwd_kernel   d_rgb_map/d_depth/d_entropy + raw, alpha, T, theta  -> g_theta [P,128] (+ base-Gaussian partials)
+//   bwd_data_kernel   g_theta -> g_hr, g_ha, g_v, g_feat, g_h[D-1..0]      (same LDS-tile / MFMA structure as forward)
+//   dw_kernel         dW = dY^T X per layer, split over P, fp32 MFMA, operands straight from HBM/L2
+//   reduce kernels    partial sums -> grad_flat (deterministic: no float atomics anywhere)
+#include "cfnerf_device.h"
 #include "cfnerf_kernels.h"
 #include "cfnerf_model.h"
+#include "cfnerf_bwd.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace cfnerf {
+
+// ================================================================================================
+// 1. loss (RUN:1026-1050): one workgroup, deterministic.
+__global__ __launch_bounds__(256)
+void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, const float* __restrict__ entropy,
+                 int64_t N, int K, float beta1, int64_t n_total, float* __restrict__ d_rgb, float* __restrict__ scalars) {
+    __shared__ double sh[2][256];
+    const float invK = 1.f / (float)K;
+    const float bw = powf(0.8f / (float)K, -1.f / 7.f);                 // torch.pow(0.8/n, tensor(-1/7))  RUN:1036
+    const float c2pi = powf(2.f * 3.14159265358979323846f, -1.5f);      // RUN:1039
+    const float gscale = 1.f / (3.f * (float)n_total);
+    double nll = 0.0, mse = 0.0;
+    for (int64_t i = threadIdx.x; i < N * 3; i += blockDim.x) {
+        const float* x = rgb + i * K;                                   // [N,3,K]: (n,c) row of K values
+        const float t = target[i];
+        float mean = 0.f;
+        for (int k = 0; k < K; ++k) mean += x[k];
+        mean *= invK;                                                   // RUN:1027
+        float var = 0.f;
+        for (int k = 0; k < K; ++k) { const float d = x[k] - mean; var += d * d; }
+        const float sd = sqrtf(var / (float)(K - 1));                   // torch.std (unbiased); K == 1 -> NaN like the reference (R4)
+        const float rgb_std = sd * (float)K / (float)(K - 1);           // RUN:1034
+        const float H = rgb_std * bw + 1e-05f;                          // RUN:1036 (detached)
+        const float c2 = c2pi / H;                                      // RUN:1039
+        const float inv2h2 = 1.f / (2.f * H * H);
+        float rsum = 0.f;
+        for (int k = 0; k < K; ++k) { const float d = x[k] - t; rsum += expf(-(d * d) * inv2h2) * c2; }
+        const float m = rsum * invK + 1e-05f;                           // RUN:1041
+        nll += -logf(m);                                                // RUN:1042
+        mse += (double)((mean - t) * (mean - t));                       // RUN:1028
+        const float gcoef = gscale * invK / (m * H * H);
+        for (int k = 0; k < K; ++k) {
+            const float d = x[k] - t;
+            d_rgb[i * K + k] = gcoef * (expf(-(d * d) * inv2h2) * c2) * d;
+        }
+    }
+    sh[0][threadIdx.x] = nll; sh[1][threadIdx.x] = mse;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { sh[0][threadIdx.x] += sh[0][threadIdx.x + d]; sh[1][threadIdx.x] += sh[1][threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nllm = sh[0][0] / (3.0 * (double)n_total), msem = sh[1][0] / (3.0 * (double)n_total);
+        const float ent = entropy ? entropy[0] : 0.f;
+        scalars[0] = (float)nllm + (beta1 != 0.f ? beta1 * ent : 0.f);  // RUN:1047-1050
+        scalars[1] = (float)nllm;
+        scalars[2] = (float)msem;
+        scalars[3] = (float)(-10.0 * log(msem) / log(10.0));            // HLP:16
+    }
+}
+
+// ================================================================================================
+// 2. tail: adjoint of raw2outputs (RUN:424-452) and of the K flows (FLW:225-268, MOD:263-286).
+//    One wave per ray, lane = sample, chunks of 64 samples walked back-to-front so the suffix sums
+//    of the transmittance adjoint are a reverse wave scan + a per-k carry.
+__global__ __launch_bounds__(kThreads)
+void tail_bwd_kernel(const TailArgs A) {
+    __shared__ float carry[kWaves][kMaxK];
+    const int lane = lane_id_opaque(), wave = wave_id();
+    const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+    if (ray >= A.N) return;
+    const int S = A.S, K = A.K;
+    const float* rr = A.rays + ray * 11;
+    const float dnorm = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);
+    const float cE = -((A.d_ent != nullptr) ? A.d_ent[0] : 0.f) / (float)((double)A.P * (double)K);
+    const bool wb = (A.flags & CFNERF_F_WHITE_BKGD) != 0;
+    const float a_mean = A.flat[0], a_std = A.flat[1];
+    const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
+    const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
+    for (int k = lane; k < K; k += 64) carry[wave][k] = 0.f;
+    float gms[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gms[i] = 0.f;
+
+    const int nch = (S + 63) / 64;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int s = ch * 64 + lane;
+        const bool valid = s < S;
+        const int64_t p = ray * (int64_t)S + (valid ? s : 0);
+        float th[84], gth[84];
+        {
+            const f32x4* tp = reinterpret_cast<const f32x4*>(A.theta + p * kThetaAll);
+#pragma unroll
+            for (int q = 0; q < 18; ++q) { const f32x4 v = tp[q]; th[q * 4] = v[0]; th[q * 4 + 1] = v[1]; th[q * 4 + 2] = v[2]; th[q * 4 + 3] = v[3]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const f32x4 v = tp[kThetaRgb / 4 + q]; th[72 + q * 4] = v[0]; th[73 + q * 4] = v[1]; th[74 + q * 4] = v[2]; th[75 + q * 4] = v[3]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 84; ++i) gth[i] = 0.f;
+        const float zv = A.z[p];
+        const float dz = (s >= S - 1) ? 1e1f : A.z[p + 1] - zv;
+        const float dist = dz * dnorm;
+
+        for (int k = 0; k < K; ++k) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(A.raw + (p * K + k) * 4);
+            const f32x2 at = *reinterpret_cast<const f32x2*>(A.at + (p * K + k) * 2);
+            const float alpha = at[0], Tt = at[1];
+            const float G0 = A.d_rgb[ray * 3 * (int64_t)K + 0 * K + k], G1 = A.d_rgb[ray * 3 * (int64_t)K + 1 * K + k],
+                        G2 = A.d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
+            const float Gd = (A.d_depth != nullptr) ? A.d_depth[ray * (int64_t)K + k] : 0.f;
+            const float c0 = sigmoid_f(rv[0]), c1 = sigmoid_f(rv[1]), c2 = sigmoid_f(rv[2]);
+            const float w = alpha * Tt;
+            float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
+            if (wb) g -= (G0 + G1 + G2);                                       // rgb_map += 1 - acc  (RUN:452)
+            const float gw = valid ? g * w : 0.f;
+            const float incl = wave_scan_add_rev(gw);                          // sum over samples >= s of this chunk
+            const float car = carry[wave][k];
+            float excl = __shfl_down(incl, 1, 64);                             // exclusive suffix WITHOUT a subtraction:
+            if (lane == 63) excl = 0.f;                                        // it is later divided by ~1e-10 for opaque samples
+            const float suffix = excl + car;                                   // sum over samples > s of the ray
+            const float tot = __shfl(incl, 0, 64);
+            if (lane == 0) carry[wave][k] = car + tot;
+            const float xk = (1.f - alpha) + 1e-10f;                           // cumprod factor of RUN:443
+            const float dalpha = g * Tt - suffix / xk;
+            const float sg = sigmoid_f(rv[3]);                                 // softplus'
+            float ga = dalpha * (1.f - alpha) * dist * sg + cE * (1.f - sg);   // + d(-mean(a - softplus a))  MOD:263
+            float gz[3] = {G0 * w * c0 * (1.f - c0) + cE * (1.f - 2.f * c0),   // + d(-mean(c - 2 softplus c)) MOD:278
+                           G1 * w * c1 * (1.f - c1) + cE * (1.f - 2.f * c1),
+                           G2 * w * c2 * (1.f - c2) + cE * (1.f - 2.f * c2)};
+            if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
+
+            // ---- recompute the flows, keeping each step's input and tanh
+            const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+            float zin[4][3], tt[4][3], ain[4], ta[4];
+            float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};
+            float a = e[3] * a_std + a_mean;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const bool odd = f & 1;
+                zin[f][0] = z[0]; zin[f][1] = z[1]; zin[f][2] = z[2]; ain[f] = a;
+                const float zp0 = odd ? z[2] : z[0], zp1 = z[1], zp2 = odd ? z[0] : z[2];
+                const float pre0 = ((th[48 + f] * zp0 + th[(1 * 3 + 0) * 4 + f] * zp1) + th[(2 * 3 + 0) * 4 + f] * zp2) + th[60 + f];
+                const float pre1 = (th[52 + f] * zp1 + th[(2 * 3 + 1) * 4 + f] * zp2) + th[64 + f];
+                const float pre2 = th[56 + f] * zp2 + th[68 + f];
+                const float t0 = tanhf(pre0), t1 = tanhf(pre1), t2 = tanhf(pre2);
+                tt[f][0] = t0; tt[f][1] = t1; tt[f][2] = t2;
+                const float u0 = (th[36 + f] * t0 + th[(0 * 3 + 1) * 4 + f] * t1) + th[(0 * 3 + 2) * 4 + f] * t2;
+                const float u1 = th[40 + f] * t1 + th[(1 * 3 + 2) * 4 + f] * t2;
+                const float u2 = th[44 + f] * t2;
+                z[0] = (odd ? u2 : u0) + z[0]; z[1] = u1 + z[1]; z[2] = (odd ? u0 : u2) + z[2];
+                ta[f] = tanhf(th[76 + f] * a + th[80 + f]);
+                a = th[72 + f] * ta[f] + a;
+            }
+            // ---- adjoint, last flow first
+#pragma unroll
+            for (int f = 3; f >= 0; --f) {
+                const bool odd = f & 1;
+                const float zp0 = odd ? zin[f][2] : zin[f][0], zp1 = zin[f][1], zp2 = odd ? zin[f][0] : zin[f][2];
+                const float t0 = tt[f][0], t1 = tt[f][1], t2 = tt[f][2];
+                const float d1_0 = th[36 + f], d1_1 = th[40 + f], d1_2 = th[44 + f];
+                const float d2_0 = th[48 + f], d2_1 = th[52 + f], d2_2 = th[56 + f];
+                const float gu0 = odd ? gz[2] : gz[0], gu1 = gz[1], gu2 = odd ? gz[0] : gz[2];   // u = flip(z-update)
+                // u_i = sum_{j>=i} R1[i][j] t_j
+                float gt0 = d1_0 * gu0;
+                float gt1 = th[(0 * 3 + 1) * 4 + f] * gu0 + d1_1 * gu1;
+                float gt2 = th[(0 * 3 + 2) * 4 + f] * gu0 + th[(1 * 3 + 2) * 4 + f] * gu1 + d1_2 * gu2;
+                gth[36 + f] += gu0 * t0; gth[40 + f] += gu1 * t1; gth[44 + f] += gu2 * t2;
+                gth[(0 * 3 + 1) * 4 + f] += gu0 * t1; gth[(0 * 3 + 2) * 4 + f] += gu0 * t2; gth[(1 * 3 + 2) * 4 + f] += gu1 * t2;
+                // log-det: ld_i = log(|q_i| + 1e-8), q_i = (1 - t_i^2) d1_i d2_i + 1     (FLW:251-259)
+                if (cE != 0.f && valid) {
+                    const float q0 = (1.f - t0 * t0) * (d1_0 * d2_0) + 1.f, q1 = (1.f - t1 * t1) * (d1_1 * d2_1) + 1.f,
+                                q2 = (1.f - t2 * t2) * (d1_2 * d2_2) + 1.f;
+                    const float gq0 = cE * copysignf(1.f, q0) / (fabsf(q0) + 1e-08f), gq1 = cE * copysignf(1.f, q1) / (fabsf(q1) + 1e-08f),
+                                gq2 = cE * copysignf(1.f, q2) / (fabsf(q2) + 1e-08f);
+                    gt0 += gq0 * (-2.f * t0 * d1_0 * d2_0); gt1 += gq1 * (-2.f * t1 * d1_1 * d2_1); gt2 += gq2 * (-2.f * t2 * d1_2 * d2_2);
+                    gth[36 + f] += gq0 * (1.f - t0 * t0) * d2_0; gth[40 + f] += gq1 * (1.f - t1 * t1) * d2_1; gth[44 + f] += gq2 * (1.f - t2 * t2) * d2_2;
+                    gth[48 + f] += gq0 * (1.f - t0 * t0) * d1_0; gth[52 + f] += gq1 * (1.f - t1 * t1) * d1_1; gth[56 + f] += gq2 * (1.f - t2 * t2) * d1_2;
+                }
+                const float gp0 = gt0 * (1.f - t0 * t0), gp1 = gt1 * (1.f - t1 * t1), gp2 = gt2 * (1.f - t2 * t2);
+                gth[60 + f] += gp0; gth[64 + f] += gp1; gth[68 + f] += gp2;                         // b
+                // pre_i = sum_{j>=i} R2[i][j] zp_j,  R2[i][i] = d2_i,  R2[i][j>i] = D[j][i]
+                gth[48 + f] += gp0 * zp0; gth[52 + f] += gp1 * zp1; gth[56 + f] += gp2 * zp2;
+                gth[(1 * 3 + 0) * 4 + f] += gp0 * zp1; gth[(2 * 3 + 0) * 4 + f] += gp0 * zp2; gth[(2 * 3 + 1) * 4 + f] += gp1 * zp2;
+                const float gzp0 = d2_0 * gp0;
+                const float gzp1 = th[(1 * 3 + 0) * 4 + f] * gp0 + d2_1 * gp1;
+                const float gzp2 = th[(2 * 3 + 0) * 4 + f] * gp0 + th[(2 * 3 + 1) * 4 + f] * gp1 + d2_2 * gp2;
+                gz[0] += odd ? gzp2 : gzp0; gz[1] += gzp1; gz[2] += odd ? gzp0 : gzp2;
+                // alpha: a' = a + d1 tanh(d2 a + b)
+                {
+                    const float d1 = th[72 + f], d2 = th[76 + f], tav = ta[f], ai = ain[f];
+                    float gta = ga * d1;
+                    gth[72 + f] += ga * tav;
+                    if (cE != 0.f && valid) {
+                        const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;
+                        const float gq = cE * copysignf(1.f, q) / (fabsf(q) + 1e-08f);
+                        gta += gq * (-2.f * tav * d1 * d2);
+                        gth[72 + f] += gq * (1.f - tav * tav) * d2;
+                        gth[76 + f] += gq * (1.f - tav * tav) * d1;
+                    }
+                    const float gpa = gta * (1.f - tav * tav);
+                    gth[80 + f] += gpa;
+                    gth[76 + f] += gpa * ai;
+                    ga += gpa * d2;
+                }
+            }
+            // base sample z0 = eps * std + mean  (MOD:239,251)
+            gms[0] += ga; gms[1] += ga * e[3];
+            gms[2] += gz[0]; gms[3] += gz[1]; gms[4] += gz[2];
+            gms[5] += gz[0] * e[0]; gms[6] += gz[1] * e[1]; gms[7] += gz[2] * e[2];
+        }
+        // diagonals were tanh-ed (MOD:341-348): gradient w.r.t. the linear head output
+#pragma unroll
+        for (int i = 36; i < 60; ++i) gth[i] *= (1.f - th[i] * th[i]);
+#pragma unroll
+        for (int i = 72; i < 80; ++i) gth[i] *= (1.f - th[i] * th[i]);
+        if (valid) {
+            f32x4* gp = reinterpret_cast<f32x4*>(A.g_theta + p * kThetaAll);
+#pragma unroll
+            for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = gth[q * 4]; v[1] = gth[q * 4 + 1]; v[2] = gth[q * 4 + 2]; v[3] = gth[q * 4 + 3]; gp[q] = v; }
+            f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+#pragma unroll
+            for (int q = 18; q < 24; ++q) gp[q] = zero;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { f32x4 v; v[0] = gth[72 + q * 4]; v[1] = gth[73 + q * 4]; v[2] = gth[74 + q * 4]; v[3] = gth[75 + q * 4]; gp[24 + q] = v; }
+#pragma unroll
+            for (int q = 27; q < 32; ++q) gp[q] = zero;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gms[i] = wave_sum(gms[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A.gms_partials[ray * 8 + i] = gms[i];
+    }
+}
+
+// ================================================================================================
+// 3. fused backward-data: per 64-point tile walk the network backwards out of the LDS tile.
+//    dX = dY W  uses the transposed packed operands (bt_*); ReLU masks come from the stashed
+//    activations; every pre-activation gradient is written out for the weight-gradient GEMM.
+__host__ __device__ inline size_t bwd_lds_bytes(int W, int ha) {
+    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4));
+}
+
+// acc (+ ReLU mask from `mask` > 0) -> LDS tile, global dY matrix, per-workgroup bias partials
+template <int NTW>
+__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], int nt_total, int nt0, int nts, float* lds_dst, int ld,
+                                          const float* __restrict__ mask, int mld, float* __restrict__ gdst, int gld,
+                                          float* __restrict__ dbp, int rows_valid) {
+    const int lane = lane_id_opaque();
+    const int rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = nt0 + j * nts;
+        if (nt >= nt_total) continue;
+        const int col = nt * 32 + (lane & 31);
+        float* lp = lds_dst + rbase * ld + col;
+        float* gp = gdst + (size_t)rbase * gld + col;
+        const float* mp = (mask != nullptr) ? mask + (size_t)rbase * mld + col : nullptr;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = rr + rbase < rows_valid;
+                float v = ok ? acc[i][j][r] : 0.f;
+                if (mp != nullptr && ok) v = (mp[(size_t)rr * mld] > 0.f) ? v : 0.f;
+                lp[rr * ld] = v;
+                if (ok) gp[(size_t)rr * gld] = v;
+                csum += v;
+            }
+        csum += __shfl_xor(csum, 32, 64);
+        if (lane < 32) dbp[col] += csum;          // this (workgroup, column) is owned by exactly one lane: no atomics
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
+void bwd_data_kernel(const BwdArgs A) {
+    constexpr int LD = act_ld(W);
+    constexpr int NT = W / 32, NTW = (NT + kWaves - 1) / kWaves, NTV = (W / 64 + kWaves - 1) / kWaves;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NetTab& T = *A.tab;
+    const int HA = T.ha_sz, HR = T.hr_sz, HLD = HA + 4, D = T.D;
+    float* act = smem;
+    float* hs = act + kTileM * LD;
+    const int tid = threadIdx.x, wave = wave_id();
+    const float* __restrict__ wp = A.wp;
+    const int64_t P = A.P;
+    float* dbp = A.dbp + (size_t)blockIdx.x * A.nb;           // this workgroup's bias-gradient partials
+    const int64_t n_tiles = (P + kTileM - 1) / kTileM;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * kTileM;
+        const int rows_valid = (int)min((int64_t)kTileM, P - p0);
+        // ---- 0. g_theta tile -> act[:, 0:128)
+        for (int idx = tid; idx < kTileM * (kThetaAll / 4); idx += kThreads) {
+            const int row = idx >> 5, q = idx & 31;
+            f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (row < rows_valid) v = *reinterpret_cast<const f32x4*>(A.g_theta + (p0 + row) * kThetaAll + q * 4);
+            *reinterpret_cast<f32x4*>(act + row * LD + q * 4) = v;
+        }
+        __syncthreads();
+        if (tid < kThetaAll) {                                 // bias gradients of the flow-parameter heads
+            float s = 0.f;
+            for (int r = 0; r < kTileM; ++r) s += act[r * LD + tid];
+            dbp[A.db_theta + tid] += s;
+        }
+        // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
+        {
+            f32x16 acc[2][1];
+            acc_zero(acc);
+            const bool is_rgb = wave < 2;
+            if (is_rgb) mma_seg<1>(acc, T.bt_fr, wave, kWaves, wp, act, LD);
+            else        mma_seg<1>(acc, T.bt_fa, wave - 2, kWaves, wp, act + kThetaRgb, LD);
+            __syncthreads();
+            if (is_rgb) store_bwd<1>(acc, T.bt_fr.nt, wave, kWaves, act, LD, nullptr, 0, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
+            else        store_bwd<1>(acc, T.bt_fa.nt, wave - 2, kWaves, hs, HLD, nullptr, 0, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
+            __syncthreads();
+        }
+        // ---- 2. dv = (dh_rgb * R) . relu'(v)
+        {
+            f32x16 acc[2][NTV];
+            acc_zero(acc);
+            mma_seg<NTV>(acc, T.bt_hr, wave, kWaves, wp, act, LD);
+            __syncthreads();
+            store_bwd<NTV>(acc, T.bt_hr.nt, wave, kWaves, act, LD, A.st_v + p0 * (W / 2), W / 2, A.g_v + p0 * (W / 2), W / 2,
+                           dbp + A.db_v, rows_valid);
+            __syncthreads();
+        }
+        // ---- 3. dfeature = dv * V[:, 0:W]        (feature_linear has no activation, MOD:176)
+        {
+            f32x16 acc[2][NTW];
+            acc_zero(acc);
+            mma_seg<NTW>(acc, T.bt_vf, wave, kWaves, wp, act, LD);
+            __syncthreads();
+            store_bwd<NTW>(acc, T.bt_vf.nt, wave, kWaves, act, LD, nullptr, 0, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
+            __syncthreads();
+        }
+        // ---- 4. dh_{D-1} = (dfeature * F + dh_alpha * A) . relu'(h_{D-1})
+        {
+            f32x16 acc[2][NTW];
+            acc_zero(acc);
+            mma_seg<NTW>(acc, T.bt_ft, wave, kWaves, wp, act, LD);
+            mma_seg<NTW>(acc, T.bt_ha, wave, kWaves, wp, hs, HLD);
+            __syncthreads();
+            store_bwd<NTW>(acc, NT, wave, kWaves, act, LD, A.st_h + ((size_t)(D - 1) * P + p0) * W, W,
+                           A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
+            __syncthreads();
+        }
+        // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
+        for (int l = D - 1; l >= 1; --l) {
+            f32x16 acc[2][NTW];
+            acc_zero(acc);
+            mma_seg<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD);
+            __syncthreads();
+            store_bwd<NTW>(acc, NT, wave, kWaves, act, LD, A.st_h + ((size_t)(l - 1) * P + p0) * W, W,
+                           A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
+            __syncthreads();
+        }
+    }
+}
+
+// ================================================================================================
+// 4. weight gradients: dW[n][k] = sum_p dY[p][n] X[p][k], fp32 MFMA, P split across workgroups.
+//    Workgroup tile 128 (n) x 256 (k): every wave owns 64 k-columns and all 128 rows (4 x 2 MFMA tiles).
+//    Operands come straight from global memory as 16-B / 8-B vectors: lane (i, kk) reads
+//    dY[p + kk][n0 + 4i .. 4i+3] and X[p + kk][k0 + 2i .. 2i+1]; MFMA tile t uses vector component t,
+//    i.e. the rows (cols) of a tile are interleaved with stride 4 (2) - a free relabelling.
+__global__ __launch_bounds__(kThreads, 2)
+void dw_kernel(const DwTile* __restrict__ tiles, int nsplit, int64_t P, int64_t p_chunk, float* __restrict__ partials,
+               int64_t n_params) {
+    const int lane = lane_id_opaque(), wave = wave_id();
+    const DwTile t = tiles[blockIdx.x / nsplit];
+    const int split = blockIdx.x % nsplit;
+    const int kw0 = t.k0 + 64 * wave;
+    if (kw0 >= t.K) return;
+    const int64_t pb = (int64_t)split * p_chunk, pe = min(P, pb + p_chunk);
+    const int i = lane & 31, kk = lane >> 5;
+    const int ncol = t.n0 + 4 * i, kcol = kw0 + 2 * i;
+    const bool n_ok = ncol + 4 <= t.Npad;          // the 16-B vector stays inside the readable part of the dY row
+    const bool k_ok = kcol + 2 <= t.Kpad;
+    const float* yp = t.dY + ncol;
+    const float* xp = t.X + kcol;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto load = [&](int64_t p, f32x4& av, f32x2& bv) {
+        const int64_t pr = p + kk;
+        av[0] = av[1] = av[2] = av[3] = 0.f; bv[0] = bv[1] = 0.f;
+        if (pr < pe) {
+            if (n_ok) av = *reinterpret_cast<const f32x4*>(yp + pr * t.ldY);
+            if (k_ok) bv = *reinterpret_cast<const f32x2*>(xp + pr * t.ldX);
+        }
+    };
+    f32x4 a0, a1, a2, a3; f32x2 b0, b1, b2, b3;
+    int64_t p = pb;
+    load(p, a0, b0); load(p + 2, a1, b1);
+    for (; p < pe; p += 8) {
+        load(p + 4, a2, b2); load(p + 6, a3, b3);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a0[tn], b0[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a0[tn], b0[1], acc[tn][1]); }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a1[tn], b1[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a1[tn], b1[1], acc[tn][1]); }
+        load(p + 8, a0, b0); load(p + 10, a1, b1);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a2[tn], b2[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a2[tn], b2[1], acc[tn][1]); }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a3[tn], b3[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a3[tn], b3[1], acc[tn][1]); }
+    }
+    // ---- write this split's partial tile in the flat gradient layout
+    float* out = partials + (size_t)split * n_params;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+            const int k = kw0 + 2 * (lane & 31) + tk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = t.n0 + 4 * frag_row(r, lane) + tn;
+                if (n < t.N && k < t.K) {
+                    int sg = 0;
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) if (q < t.nseg && n >= t.seg_row[q]) sg = q;
+                    out[(size_t)t.seg_dst[sg] + (size_t)(n - t.seg_row[sg]) * t.dst_ld + t.dst_col + k] = acc[tn][tk][r];
+                }
+            }
+        }
+}
+
+// ================================================================================================
+// 5. reductions into grad_flat
+__global__ void reduce_weights_kernel(const float* __restrict__ partials, int nsplit, int64_t n_params, float* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_params) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partials[(size_t)k * n_params + i];
+    grad[i] = s;
+}
+
+__global__ void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const BiasMap* __restrict__ maps, int n_maps,
+                                   float* __restrict__ grad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;      // column of the bias partial table
+    if (j >= nb) return;
+    int m = -1;
+    for (int q = 0; q < n_maps; ++q) if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) m = q;
+    if (m < 0) return;
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += dbp[(size_t)w * nb + j];
+    grad[maps[m].dst + (j - maps[m].col0)] = s;
+}
+
+// base-Gaussian parameters: chain through z0 = eps*std + mean (tail partials) + d mean(base log-normal)/d std = -1/std
+__global__ void reduce_gms_kernel(const float* __restrict__ gms, int64_t n_rows, const float* __restrict__ flat,
+                                  const float* __restrict__ d_ent, float* __restrict__ grad) {
+    __shared__ double sh[8][256];
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t r = threadIdx.x; r < n_rows; r += blockDim.x)
+        for (int i = 0; i < 8; ++i) s[i] += gms[r * 8 + i];
+    for (int i = 0; i < 8; ++i) sh[i][threadIdx.x] = s[i];
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) for (int i = 0; i < 8; ++i) sh[i][threadIdx.x] += sh[i][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ge = d_ent ? d_ent[0] : 0.f;
+        grad[0] = (float)sh[0][0];                                       // alpha_mean
+        grad[1] = (float)sh[1][0] + ge * (-1.f / flat[1]);               // alpha_std: + d mean(base_a)/d std
+        for (int c = 0; c < 3; ++c) {
+            grad[2 + c] = (float)sh[2 + c][0];                           // rgb_mean
+            grad[5 + c] = (float)sh[5 + c][0] + ge * (-1.f / (3.f * flat[5 + c]));   // rgb_std (mean over 3 channels, MOD:283,286)
+        }
+    }
+}
+
+// ================================================================================================
+// 6. Adam (torch.optim.Adam defaults, RUN:339)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = 0.9f * m[i] + (1.f - 0.9f) * gi;
+    const float vi = 0.999f * v[i] + (1.f - 0.999f) * (gi * gi);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + 1e-08f;
+    p[i] = p[i] - lr_over_bc1 * (mi / denom);
+}
+
+// ================================================================================================
+// host side
+static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int n_cu, hipStream_t st, int* grid_out) {
+    const size_t lds = bwd_lds_bytes(ht.W, ht.ha_sz);
+    const void* fn = nullptr;
+    switch (ht.W) {
+        case 64: fn = reinterpret_cast<const void*>(bwd_data_kernel<64>); break;
+        case 128: fn = reinterpret_cast<const void*>(bwd_data_kernel<128>); break;
+        case 256: fn = reinterpret_cast<const void*>(bwd_data_kernel<256>); break;
+        case 512: fn = reinterpret_cast<const void*>(bwd_data_kernel<512>); break;
+        default: return hipErrorInvalidValue;
+    }
+    static size_t lds_set[4] = {0, 0, 0, 0};
+    const int wi = ht.W == 64 ? 0 : ht.W == 128 ? 1 : ht.W == 256 ? 2 : 3;
+    if (lds_set[wi] != lds) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set[wi] = lds;
+    }
+    const int64_t tiles = (a.P + kTileM - 1) / kTileM;
+    int grid = (int)std::min<int64_t>(tiles, (int64_t)a.n_wg);
+    if (grid_out) *grid_out = grid;
+    void* args[] = {const_cast<BwdArgs*>(&a)};
+    return hipLaunchKernel(fn, dim3(grid), dim3(kThreads), args, lds, st);
+}
+
+}  // namespace cfnerf
+
+using namespace cfnerf;
+
+static thread_local char g_berr[512] = "";
+extern "C" const char* cfnerf_last_error(void);
+// error text is shared with the ABI file through this hook
+extern "C" void cfnerf_set_error_(const char* msg);
+static int bfail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_berr, sizeof g_berr, fmt, ap);
+    va_end(ap);
+    cfnerf_set_error_(g_berr);
+    return code;
+}
+#define BHIP(expr)                                                                               \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return bfail(CFNERF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// build (once per model) the weight-gradient tile list, the bias map and their device copies
+static int ensure_bwd_plan(cfnerf_model* m) {
+    BwdPlan& B = m->bwd;
+    if (B.built) return 0;
+    const cfnerf_cfg& c = m->cfg;
+    const ParamLayout& L = m->layout;
+    const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
+    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    // bias partial table columns
+    int nb = 0;
+    B.db_h = nb; nb += D * W;
+    B.db_feat = nb; nb += W;
+    B.db_v = nb; nb += W / 2;
+    B.db_ha = nb; nb += pad_to(HA, 32);
+    B.db_hr = nb; nb += pad_to(HR, 32);
+    B.db_theta = nb; nb += kThetaAll;
+    B.nb = nb;
+    char key[64];
+    auto bmap = [&](int col0, int count, const char* k) {
+        BiasMap bm; bm.col0 = col0; bm.count = count; bm.dst = (uint32_t)L.off(k);
+        B.bias_maps.push_back(bm);
+    };
+    for (int l = 0; l < D; ++l) { std::snprintf(key, sizeof key, "pts_linears.%d.bias", l); bmap(B.db_h + l * W, W, key); }
+    bmap(B.db_feat, W, "feature_linear.bias");
+    bmap(B.db_v, W / 2, "views_linears.0.bias");
+    bmap(B.db_ha, HA, "h_alpha_linear.bias");
+    bmap(B.db_hr, HR, "h_rgb_linear.bias");
+    bmap(B.db_theta + 0, 9 * F, "flows_rgb.amor_d.bias");
+    bmap(B.db_theta + 9 * F, 3 * F, "flows_rgb.amor_diag1.0.bias");
+    bmap(B.db_theta + 12 * F, 3 * F, "flows_rgb.amor_diag2.0.bias");
+    bmap(B.db_theta + 15 * F, 3 * F, "flows_rgb.amor_b.bias");
+    bmap(B.db_theta + kThetaRgb + 0, F, "flows_alpha.amor_diag1.0.bias");
+    bmap(B.db_theta + kThetaRgb + F, F, "flows_alpha.amor_diag2.0.bias");
+    bmap(B.db_theta + kThetaRgb + 2 * F, F, "flows_alpha.amor_b.bias");
+    B.built = true;
+    return 0;
+}
+
+// one weight-gradient job -> tiles of 128 x 256
+static void add_job(std::vector<DwTile>& tiles, const float* dY, int ldY, int Nread, int N, const float* X, int ldX, int K, int Kvalid,
+                    int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
+    for (int n0 = 0; n0 < N; n0 += 128)
+        for (int k0 = 0; k0 < Kvalid; k0 += 256) {
+            DwTile t{};
+            t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
+            t.nseg = nseg;
+            for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
+            t.dst_ld = dst_ld; t.dst_col = dst_col;
+            tiles.push_back(t);
+        }
+}
 
 extern "C" {
-int cfnerf_loss_fwd_bwd(const float*, const float*, const float*, int64_t, int, float, int64_t, float*, float*, cfnerf_stream) { return CFNERF_E_UNSUPPORTED; }
-int cfnerf_render_bwd(cfnerf_model*, const float*, const float*, const float*, float*, cfnerf_stream) { return CFNERF_E_UNSUPPORTED; }
-int cfnerf_adam_step(cfnerf_model*, float*, const float*, float*, float*, int64_t, float, float, cfnerf_stream) { return CFNERF_E_UNSUPPORTED; }
+
+int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K, float beta1,
+                        int64_t n_total, float* d_rgb_map, float* scalars_out, cfnerf_stream s) {
+    if (N < 0 || K < 1 || n_total < N) return bfail(CFNERF_E_INVALID, "bad N/K/n_total");
+    if (N == 0) return CFNERF_OK;
+    if (!rgb_map || !target || !d_rgb_map || !scalars_out) return bfail(CFNERF_E_INVALID, "NULL argument");
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, rgb_map, target, entropy, N, K, beta1, n_total,
+                       d_rgb_map, scalars_out);
+    BHIP(hipGetLastError());
+    return CFNERF_OK;
 }
+
+int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_depth_map, const float* d_entropy,
+                      float* grad_flat, cfnerf_stream s) {
+    if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
+    Stash& q = m->stash;
+    if (!q.valid) return bfail(CFNERF_E_INVALID, "no stashed forward: call cfnerf_render_fwd with CFNERF_F_STASH first");
+    if (q.S > 4096) return bfail(CFNERF_E_UNSUPPORTED, "backward supports S <= 4096");
+    hipStream_t st = (hipStream_t)s;
+    if (int rc = ensure_bwd_plan(m)) return rc;
+    BwdPlan& B = m->bwd;
+    const cfnerf_cfg& c = m->cfg;
+    const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
+    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    const int64_t N = q.N, P = q.N * (int64_t)q.S, n_params = m->layout.total;
+    const ParamLayout& L = m->layout;
+
+    // ---- workspace sizes that depend on the batch
+    const int n_wg = m->n_cu * ((W <= 256) ? 2 : 1);
+    int nsplit = 16;
+    while (nsplit > 1 && P / nsplit < 1024) nsplit >>= 1;
+    int64_t p_chunk = (P + nsplit - 1) / nsplit;
+    p_chunk = (p_chunk + 7) / 8 * 8;
+    if (B.dbp_wg < n_wg || !B.d_dbp) {
+        if (B.d_dbp) hipFree(B.d_dbp);
+        BHIP(hipMalloc(&B.d_dbp, (size_t)n_wg * B.nb * sizeof(float)));
+        B.dbp_wg = n_wg;
+    }
+    if (B.partials_split < nsplit || !B.d_partials) {
+        if (B.d_partials) hipFree(B.d_partials);
+        BHIP(hipMalloc(&B.d_partials, (size_t)nsplit * n_params * sizeof(float)));
+        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)nsplit * n_params * sizeof(float), st));   // bias/dead slots stay 0 forever
+        B.partials_split = nsplit;
+    }
+    if (!B.d_bias_maps) {
+        BHIP(hipMalloc(&B.d_bias_maps, B.bias_maps.size() * sizeof(BiasMap)));
+        BHIP(hipMemcpyAsync(B.d_bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap), hipMemcpyHostToDevice, st));
+    }
+    // ---- weight-gradient tile list (pointers depend on the stash allocation)
+    if (B.tiles_for != q.h || B.tiles_P != P) {
+        std::vector<DwTile> tiles;
+        char key[64];
+        const int one_row[1] = {0};
+        for (int l = 0; l < D; ++l) {
+            std::snprintf(key, sizeof key, "pts_linears.%d.weight", l);
+            const uint32_t dst[1] = {(uint32_t)L.off(key)};
+            const float* dY = q.g_h + (size_t)l * P * W;
+            if (l == 0) {
+                add_job(tiles, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
+            } else if (l - 1 == skip) {
+                add_job(tiles, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
+                add_job(tiles, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
+            } else {
+                add_job(tiles, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
+            }
+        }
+        const float* hlast = q.h + (size_t)(D - 1) * P * W;
+        { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(tiles, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
+        { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(tiles, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
+        {
+            const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
+            add_job(tiles, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
+            add_job(tiles, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
+        }
+        { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(tiles, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
+        {
+            const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
+            const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
+                                     (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
+            add_job(tiles, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
+        }
+        {
+            const int rows[3] = {0, F, 2 * F};
+            const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
+                                     (uint32_t)L.off("flows_alpha.amor_b.weight")};
+            add_job(tiles, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
+        }
+        if (B.d_tiles) hipFree(B.d_tiles);
+        BHIP(hipMalloc(&B.d_tiles, tiles.size() * sizeof(DwTile)));
+        BHIP(hipMemcpyAsync(B.d_tiles, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
+        BHIP(hipStreamSynchronize(st));       // `tiles` is a host temporary
+        B.n_tiles = (int)tiles.size();
+        B.tiles_for = q.h; B.tiles_P = P;
+    }
+
+    // ---- 1. tail
+    TailArgs ta{};
+    ta.raw = q.raw_used; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
+    ta.d_rgb = d_rgb_map; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
+    ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
+    if (m->timing) BHIP(hipEventRecord(m->ev0[1], st));
+    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
+    BHIP(hipGetLastError());
+    if (m->timing) BHIP(hipEventRecord(m->ev1[1], st));
+
+    // ---- 2. fused backward-data (+ bias partials)
+    BHIP(hipMemsetAsync(B.d_dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
+    BwdArgs ba{};
+    ba.tab = m->d_tab; ba.wp = m->d_packed; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
+    ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
+    ba.st_v = q.v; ba.st_h = q.h; ba.dbp = B.d_dbp;
+    ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
+    int grid_bd = 0;
+    if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));
+    BHIP(launch_bwd_data(ba, m->plan.tab, m->n_cu, st, &grid_bd));
+    if (m->timing) BHIP(hipEventRecord(m->ev1[2], st));
+
+    // ---- 3. weight gradients + reductions
+    if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
+    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)(B.n_tiles * nsplit)), dim3(kThreads), 0, st, B.d_tiles, nsplit, P, p_chunk,
+                       B.d_partials, n_params);
+    BHIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, nsplit,
+                       n_params, grad_flat);
+    BHIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 255) / 256)), dim3(256), 0, st, B.d_dbp, grid_bd, B.nb,
+                       B.d_bias_maps, (int)B.bias_maps.size(), grad_flat);
+    BHIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N, m->flat, d_entropy, grad_flat);
+    BHIP(hipGetLastError());
+    if (m->timing) BHIP(hipEventRecord(m->ev1[3], st));
+    return CFNERF_OK;
+}
+
+int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat, float* exp_avg, float* exp_avg_sq,
+                     int64_t step, float lr, float grad_scale, cfnerf_stream s) {
+    if (!m || !flat_params || !grad_flat || !exp_avg || !exp_avg_sq) return bfail(CFNERF_E_INVALID, "NULL argument");
+    if (step < 1) return bfail(CFNERF_E_INVALID, "step is 1-based");
+    hipStream_t st = (hipStream_t)s;
+    const int64_t n = m->layout.total;
+    const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
+    if (m->timing) BHIP(hipEventRecord(m->ev0[4], st));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat_params, grad_flat, exp_avg, exp_avg_sq, n,
+                       (float)(lr / bc1), (float)(1.0 / std::sqrt(bc2)), grad_scale);
+    BHIP(hipGetLastError());
+    int rc = cfnerf_model_set_params(m, flat_params, s);
+    if (m->timing) BHIP(hipEventRecord(m->ev1[4], st));
+    return rc;
+}
+
+}  // extern "C"

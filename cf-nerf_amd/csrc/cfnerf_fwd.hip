@@ -288,6 +288,10 @@ void fused_fwd_kernel(const FwdArgs A) {
                         const float Tcar = cp[5];
                         const float wgt = alpha * (Tcar * excl);
                         if (A.weights != nullptr && valid) A.weights[(p0 + row) * (int64_t)K + k] = wgt;
+                        if (A.st_at != nullptr && valid) {
+                            f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
+                            *reinterpret_cast<f32x2*>(A.st_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
+                        }
                         const float s0 = wave_sum(wgt * sigmoid_f(z[0]));                          // RUN:431,444
                         const float s1 = wave_sum(wgt * sigmoid_f(z[1]));
                         const float s2 = wave_sum(wgt * sigmoid_f(z[2]));

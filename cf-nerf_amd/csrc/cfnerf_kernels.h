@@ -27,6 +27,7 @@ struct FwdArgs {
     float* ent_partials;                 // [grid,2]  (TRAIN)
     // activation stash for the backward pass (all optional, row-major per point)
     float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
+    float *st_at;                        // [P,K,2] alpha, transmittance T of the composite
 };
 
 hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int n_cu, hipStream_t st, int* grid_out);

@@ -44,8 +44,8 @@ inline const char* validate_cfg(const cfnerf_cfg& c) {
         return "netwidth must be 64, 128, 256 or 512";
     if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";
     if (c.multires_views < 1 || enc_ch(c.multires_views) > 32) return "multires_views must be in [1,4]";
-    if (c.h_alpha_size % 8 || c.h_alpha_size < 8 || c.h_alpha_size > 64) return "h_alpha_size must be a multiple of 8 in [8,64]";
-    if (c.h_rgb_size % 8 || c.h_rgb_size < 8 || c.h_rgb_size > 64) return "h_rgb_size must be a multiple of 8 in [8,64]";
+    if (c.h_alpha_size != 32 && c.h_alpha_size != 64) return "h_alpha_size must be 32 or 64";
+    if (c.h_rgb_size != 32 && c.h_rgb_size != 64) return "h_rgb_size must be 32 or 64";
     if (c.n_flows != 4) return "only n_flows == 4 is built";
     return nullptr;
 }

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "cfnerf_layout.h"
+#include "cfnerf_bwd.h"
 
 namespace cfnerf {
 
@@ -24,6 +25,9 @@ struct Stash {
     float *z = nullptr;      // [P]      z_vals
     float *raw = nullptr;    // [P,K,4]  (used when the caller did not ask for raw)
     float *rays = nullptr;   // [N,11]
+    float *at = nullptr;     // [P,K,2] alpha, T
+    float *dbp = nullptr;    // [n_wg, NB] per-workgroup bias-gradient partials
+    float *gms = nullptr;    // [n_waves, 8] base-Gaussian gradient partials
     // backward workspaces (same row-major-per-point convention)
     float *g_theta = nullptr;   // [P,128]  d loss / d theta (pre-tanh for the diagonal columns)
     float *g_hr = nullptr;      // [P,HR]
@@ -40,7 +44,7 @@ struct Stash {
     size_t partial_floats = 0;
 
     void release() {
-        float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays,
+        float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays, &at, &dbp, &gms,
                          &g_theta, &g_hr, &g_ha, &g_v, &g_feat, &g_h, &partials};
         for (float** p : all) { if (*p) hipFree(*p); *p = nullptr; }
         cap_P = cap_N = 0; cap_K = 0; bytes = 0; valid = false; partial_floats = 0;
@@ -61,7 +65,7 @@ struct Stash {
         bool ok = al(&enc, (size_t)P * 64) && al(&gd, (size_t)P * 32) && al(&h, (size_t)D * P * W) && al(&feat, (size_t)P * W) &&
                   al(&v, (size_t)P * (W / 2)) && al(&ha, (size_t)P * c.h_alpha_size) && al(&hr, (size_t)P * c.h_rgb_size) &&
                   al(&theta, (size_t)P * kThetaAll) && al(&z, (size_t)P) && al(&raw, (size_t)P * k * 4) &&
-                  al(&rays, (size_t)n * 11) && al(&g_theta, (size_t)P * kThetaAll) && al(&g_hr, (size_t)P * c.h_rgb_size) &&
+                  al(&rays, (size_t)n * 11) && al(&at, (size_t)P * k * 2) && al(&gms, (size_t)(n + 8) * 8) && al(&g_theta, (size_t)P * kThetaAll) && al(&g_hr, (size_t)P * c.h_rgb_size) &&
                   al(&g_ha, (size_t)P * c.h_alpha_size) && al(&g_v, (size_t)P * (W / 2)) && al(&g_feat, (size_t)P * W) &&
                   al(&g_h, (size_t)D * P * W);
         if (!ok) { release(); return CFNERF_E_NOMEM; }
@@ -85,6 +89,7 @@ struct cfnerf_model {
     float* d_eps = nullptr;               // eps of the stashed forward
     float* d_scratch_ent = nullptr;
     cfnerf::Stash stash;
+    cfnerf::BwdPlan bwd;
     std::vector<void*> owned;             // misc device allocations freed at destroy
     bool timing = false;
     hipEvent_t ev0[cfnerf::kNumTimers]{}, ev1[cfnerf::kNumTimers]{};

@@ -1,0 +1,130 @@
+"""Train step of the CF-NeRF hot path on the HIP kernels (reference: train() inner loop, RUN:1013-1077).
+
+One process per GPU.  A step is: ray set-up -> fused forward (activations stashed) -> KDE-NLL loss
+(+ beta1 * entropy) -> backward -> ONE all-reduce (sum) of the flat gradient over RCCL when
+world_size > 1 -> fused Adam on the flat buffers -> re-pack.  Rays are sharded by the caller
+(rank r renders its own N_rand rays); every rank holds the full weights and applies the same update.
+
+Gradient normalisation across ranks: the reference's losses are means over rays / points
+(RUN:1042,1045).  Each rank computes the gradient of  nll_local_sum / (3 * N_total) + (beta1 / world) *
+entropy_local, so the SUM over ranks is the gradient of the global means for equal shards.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .api import NeRF_Flows, _f32c, _unwrap
+
+
+def backward_available() -> bool:
+    """True when libcfnerf_hip.so carries the real backward (an empty batch is accepted)."""
+    rc = L.lib().cfnerf_loss_fwd_bwd(None, None, None, 0, 2, C.c_float(0.0), 0, None, None, None)
+    return rc == 0
+
+
+def shard_bounds(n_rays: int, rank: int, world: int):
+    """Contiguous equal shards (the reference's DataParallel splits the same way along dim 0)."""
+    if n_rays % world:
+        raise ValueError(f"N_rand ({n_rays}) must be divisible by world_size ({world})")
+    per = n_rays // world
+    return rank * per, (rank + 1) * per
+
+
+def lr_at(lrate: float, lrate_decay: int, start: int, t: int) -> float:
+    """Learning rate used by the t-th optimiser step of this run (RUN:1073-1077: the decayed rate is
+    written to the param groups AFTER optimizer.step(), computed from the current global_step)."""
+    if t == 0:
+        return lrate
+    return lrate * (0.1 ** ((start + t - 1) / (lrate_decay * 1000)))
+
+
+def allreduce_sum_(grad: torch.Tensor, world: int, group=None):
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    return grad
+
+
+class Trainer:
+    def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0):
+        self.net: NeRF_Flows = _unwrap(net)
+        dev = self.net.flat.device
+        self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
+        self.world, self.group, self.start = int(world_size), group, int(start)
+        n = self.net.n_params
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.d_ent = torch.tensor([self.beta1 / self.world], device=dev)
+        self.scalars = torch.zeros(4, device=dev)          # loss, loss_nll, mse, psnr (local shard contribution)
+        self.entropy = torch.zeros(1, device=dev)
+        self.t = 0
+        self._buf_n = None
+
+    def _buffers(self, N, K):
+        if self._buf_n != (N, K):
+            dev = self.net.flat.device
+            self.packed = torch.empty(N, 11, device=dev)
+            self.rgb_map = torch.empty(N, 3, K, device=dev)
+            self.disp = torch.empty(N, K, device=dev)
+            self.depth = torch.empty(N, K, device=dev)
+            self.d_rgb = torch.empty(N, 3, K, device=dev)
+            self._buf_n = (N, K)
+
+    def forward_backward(self, H, W, focal, rays, target, t_rand=None, eps=None, near=0., far=1., ndc=True,
+                         lindisp=False, white_bkgd=False, perturb=1., t_vals=None, **_ignored):
+        """Forward + loss + backward of this rank's shard.  Leaves the (un-reduced) gradient in ``self.grad``."""
+        net, lib = self.net, L.lib()
+        dev = net.flat.device
+        rays_o, rays_d = rays
+        ro, rd = _f32c(rays_o.reshape(-1, 3)), _f32c(rays_d.reshape(-1, 3))
+        N, K = rd.shape[0], net.K_samples
+        if t_vals is None:
+            if not hasattr(self, "_tv"):
+                from .api import t_vals_table
+                self._tv = t_vals_table(dev)
+            t_vals = self._tv
+        S = t_vals.shape[0]
+        self._buffers(N, K)
+        st = L.stream()
+        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, int(bool(ndc)), float(near), float(far),
+                                      L.ptr(self.packed), st), "cfnerf_rays_setup")
+        if perturb > 0. and t_rand is None:
+            t_rand = torch.rand(N, S, device=dev)
+        if perturb <= 0.:
+            t_rand = None
+        if eps is None:
+            eps = net.draw_eps()
+        eps = _f32c(eps)
+        net._sync()
+        flags = L.F_STASH | L.F_TRAIN | (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0)
+        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(_f32c(t_rand) if t_rand is not None else None),
+                                      L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
+                                      None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
+        L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
+                                        C.c_float(self.beta1), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
+                "cfnerf_loss_fwd_bwd")
+        L.check(lib.cfnerf_render_bwd(net.handle, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
+                                      L.ptr(self.grad), st), "cfnerf_render_bwd")
+        return self.grad
+
+    def step(self, H, W, focal, rays, target, **kw):
+        """One full train step.  Returns the device tensor [loss, loss_nll, mse, psnr] of the local shard."""
+        kw = {k: v for k, v in kw.items() if k in ("t_rand", "eps", "near", "far", "ndc", "lindisp", "white_bkgd", "perturb", "t_vals")}
+        self.forward_backward(H, W, focal, rays, target, **kw)
+        allreduce_sum_(self.grad, self.world, self.group)
+        lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
+        self.t += 1
+        net = self.net
+        L.check(L.lib().cfnerf_adam_step(net.handle, L.ptr(net.flat.data), L.ptr(self.grad), L.ptr(self.exp_avg),
+                                         L.ptr(self.exp_avg_sq), self.t, C.c_float(lr), C.c_float(1.0), L.stream()),
+                "cfnerf_adam_step")
+        net.mark_packed()
+        return self.scalars
+
+    @property
+    def global_step(self):
+        return self.start + self.t

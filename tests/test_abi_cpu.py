@@ -45,7 +45,7 @@ def test_flat_layout_is_state_dict_order(W, ha, hr):
 def test_unsupported_configs_are_rejected_loudly():
     lib = L.lib()
     for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 3), L.Cfg(8, 256, 11, 4, 32, 64, 4),
-                L.Cfg(1, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 30, 64, 4)):
+                L.Cfg(1, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4)):
         assert lib.cfnerf_param_count(C.byref(bad)) < 0
         assert lib.cfnerf_last_error() != b""
 
@@ -62,7 +62,7 @@ def _decode(packed, w_off, kc, nt):
     return M
 
 
-@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 48)])
+@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 32)])
 def test_packed_operands_decode_to_the_weights(W, ha, hr):
     lib = C.CDLL(L.LIB_PATH)
     cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)

@@ -1,0 +1,96 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU semantics of cf-nerf_amd/train.py: rays sharded per rank,
+each rank differentiates  nll_local_sum / (3 N_total) + (beta1 / world) * entropy_local, ONE all-reduce(sum)
+of the flat gradient reproduces the single-process gradient of the global means.  The per-rank arithmetic is
+played by the CPU oracle here (the HIP kernels need a GPU); the sharding / normalisation / collective code is
+the product's (shard_bounds, allreduce_sum_, lr_at)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cfnerf_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat(grads, cfg):
+    out = []
+    for k, shp in O.param_shapes(cfg).items():
+        g = grads[k]
+        out.append(torch.zeros(int(np.prod(shp))) if g is None else g.reshape(-1))
+    return torch.cat(out)
+
+
+def _problem():
+    cfg = O.OracleCfg(netwidth=64, K_samples=3)
+    rng = np.random.default_rng(0)
+    N = 8
+    o = torch.tensor(rng.uniform(-0.2, 0.2, (N, 3)), dtype=torch.float32)
+    d = torch.tensor(rng.standard_normal((N, 3)) * 0.2 + np.array([0, 0, -1.0]), dtype=torch.float32)
+    packed = O.pack_rays(378, 504, 407.5, o, d, True, 0., 1.)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((3, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    return cfg, O.make_params(cfg, 3), packed, t_rand, ea, er, target
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cfnerf_amd.train as TR
+    torch.set_num_threads(2)
+    cfg, p, packed, t_rand, ea, er, target = _problem()
+    lo, hi = TR.shard_bounds(packed.shape[0], rank, world)
+    beta1 = 0.05
+    # local shard, same latent samples on every rank
+    scal, grads, _ = O.train_step(p, packed[lo:hi], target[lo:hi], cfg, ea, er, t_rand[lo:hi], beta1)
+    g = _flat(grads, cfg) / world             # = grad of nll_local_sum/(3 N_total) + (beta1/world) entropy_local
+    TR.allreduce_sum_(g, world)
+    if rank == 0:
+        q.put(g.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_ray_sharding_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    g2 = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    cfg, p, packed, t_rand, ea, er, target = _problem()
+    scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, 0.05)
+    g1 = _flat(grads, cfg).numpy()
+    scale = np.abs(g1).max()
+    assert np.abs(g2 - g1).max() <= 2e-5 * scale + 1e-9, np.abs(g2 - g1).max() / scale
+
+
+def test_shard_bounds_and_lr_schedule():
+    import cfnerf_amd.train as TR
+    assert [TR.shard_bounds(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
+    try:
+        TR.shard_bounds(10, 0, 4)
+        assert False
+    except ValueError:
+        pass
+    # RUN:1073-1077: lr = lrate * 0.1 ** (global_step / (lrate_decay * 1000)), applied after the step
+    assert TR.lr_at(5e-4, 250, 0, 0) == 5e-4
+    assert abs(TR.lr_at(5e-4, 250, 0, 250001) - 5e-5) < 1e-12
+    for s in (0, 10, 1000):
+        assert abs(TR.lr_at(5e-4, 250, 100, s + 1) - O.lr_schedule(5e-4, 250, 100 + s)) < 1e-15

@@ -1,0 +1,157 @@
+"""-m gpu: the train step on the HIP kernels (loss RUN:1026-1050, backward RUN:1066, Adam RUN:339,1067)
+against gradients captured from the real reference and against the CPU oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+import cfnerf_amd
+from cfnerf_amd import train as TR
+from oracle import cfnerf_oracle as O
+from util_hip import build_model, close, fern_rays
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.tensor(np.asarray(a))
+DEV = "cuda"
+
+# Gradient tolerance: relative to the largest entry of each tensor (sums over 4k-130k points in a different
+# order than the reference), plus an element-wise relative part.
+G_ATOL_REL, G_RTOL = 2e-4, 2e-3
+
+
+def grad_close(g, ref, what):
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(float(np.abs(ref).max()), 1e-8)
+    close(g, ref, atol=G_ATOL_REL * scale, rtol=G_RTOL, what=what)
+
+
+def cfg_from(g):
+    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]))
+
+
+@pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
+def test_train_step_vs_reference_golden(golden, tag):
+    g = golden(f"g57_render_{tag}")
+    cfg = cfg_from(g)
+    over = dict(no_ndc=not bool(g["ndc"]), lindisp=bool(g["lindisp"]), white_bkgd=bool(g["white_bkgd"]))
+    _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]), **over)
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    rays = T(g["rays"]).to(DEV)
+    tr = TR.Trainer(net, lrate=5e-4, beta1=float(g["beta1"]))
+    eps = torch.cat([T(g["eps_rgb"]), T(g["eps_alpha"])], -1).to(DEV)
+    kw = dict(t_rand=T(g["t_rand"]).to(DEV), eps=eps, near=float(g["near"]), far=float(g["far"]), ndc=bool(g["ndc"]),
+              lindisp=bool(g["lindisp"]), white_bkgd=bool(g["white_bkgd"]))
+    grad = tr.forward_backward(H, W, focal, rays, T(g["target"]).to(DEV), **kw).clone()
+    sc = tr.scalars.cpu().numpy()
+    close(sc[1], g["loss_nll"], atol=1e-5, rtol=1e-4, what="loss_nll")
+    close(sc[0], g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    close(sc[2], g["mse"], atol=1e-6, rtol=1e-4, what="mse")
+    close(sc[3], g["psnr"], atol=1e-4, rtol=1e-4, what="psnr")
+    close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    n = 0
+    for key, (off, cnt) in net.layout.items():
+        gk = grad[off:off + cnt].cpu().numpy()
+        if ("grad." + key) in g:
+            grad_close(gk.reshape(g["grad." + key].shape), g["grad." + key], "grad " + key)
+            n += 1
+        elif ("gradrows." + key) in g:
+            ref = g["gradrows." + key]
+            full = gk.reshape(-1, ref.shape[1])
+            scale = float(g["gradnorm." + key]) / np.sqrt(full.size)       # rms entry of the full tensor
+            close(full[:2], ref, atol=G_ATOL_REL * 10 * scale, rtol=G_RTOL, what="gradrows " + key)
+            close(np.linalg.norm(full.astype(np.float64)), g["gradnorm." + key], atol=0, rtol=1e-3, what="gradnorm " + key)
+            n += 1
+        else:
+            assert key in set(g["dead_params"].tolist()), key
+            assert not gk.any(), f"dead parameter {key} must get a zero gradient"
+    assert n >= 30
+    # one fused Adam step reproduces the reference optimiser (RUN:339,1067)
+    tr.step(H, W, focal, rays, T(g["target"]).to(DEV), **kw)
+    for key in net.layout:
+        if ("adam1." + key) in g:
+            close(net.view(key), g["adam1." + key], atol=2e-5, rtol=1e-4, what="adam " + key)
+
+
+@pytest.mark.parametrize("W,K,N", [(256, 4, 48), (128, 8, 40), (512, 2, 16)])
+def test_gradients_vs_oracle(W, K, N):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
+    _, kw_train, _, model, p, _ = build_model(cfg, 500 + W + K)
+    net = model.module
+    rng = np.random.default_rng(W + N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    beta1 = 0.05
+    tr = TR.Trainer(net, beta1=beta1)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV),
+                               eps=torch.cat([er, ea], -1).to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1)
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    for key, (off, cnt) in net.layout.items():
+        if grads[key] is None:
+            assert not grad[off:off + cnt].any()
+        else:
+            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key)
+
+
+def test_autograd_path_matches_fused_trainer():
+    """render() under autograd + the reference's loss lines written in torch + loss.backward() (the drop-in
+    training loop) gives the same gradient as the fused Trainer."""
+    import math
+    cfg = O.OracleCfg(netwidth=64, K_samples=4)
+    _, kw_train, _, model, p, optimizer = build_model(cfg, 66)
+    net = model.module
+    rng = np.random.default_rng(1)
+    N, K, beta1 = 32, 4, 0.01
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    rays = rays.to(DEV)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target_s = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32).to(DEV)
+    rgbs, disp, depth, extras = cfnerf_amd.render(H, Wd, focal, chunk=8192, rays=rays, verbose=False, retraw=False,
+                                                  t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    eps_ = 1e-05
+    n = K
+    rgb_std = torch.std(rgbs, -1) * n / (n - 1)
+    H_sqrt = (rgb_std.detach() * torch.pow(torch.tensor(0.8 / n), torch.tensor(-1 / 7)).to(DEV) + eps_)[..., None]
+    r1 = torch.exp(-((rgbs - target_s[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+    r2 = torch.pow(torch.tensor(2 * math.pi), -1.5).to(DEV) / H_sqrt
+    loss_nll = -torch.log((r1 * r2).mean(-1) + eps_).mean()
+    loss = loss_nll + beta1 * extras['loss_entropy'].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    g_auto = net.flat.grad.clone()
+    tr = TR.Trainer(net, beta1=beta1)
+    g_fused = tr.forward_backward(H, Wd, focal, rays, target_s, t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV))
+    scale = float(g_fused.abs().max())
+    close(g_auto, g_fused, atol=1e-5 * scale, rtol=1e-4, what="autograd vs fused gradient")
+    close(loss, tr.scalars[0], atol=1e-6, rtol=1e-5, what="loss")
+    before = net.flat.detach().clone()
+    optimizer.step()                                   # torch.optim.Adam on the flat parameter (RUN:339)
+    assert not torch.equal(before, net.flat.detach())
+    with torch.no_grad():                              # the next launch re-packs automatically
+        r2_ = cfnerf_amd.render(H, Wd, focal, rays=rays, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    assert not torch.equal(r2_[0], rgbs.detach())
+
+
+def test_training_reduces_the_loss():
+    cfg = O.OracleCfg(netwidth=128, K_samples=4)
+    _, kw_train, _, model, p, _ = build_model(cfg, 12)
+    net = model.module
+    rng = np.random.default_rng(2)
+    N = 256
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    target = torch.tensor(rng.uniform(0.2, 0.8, (N, 3)), dtype=torch.float32).to(DEV)
+    tr = TR.Trainer(net, lrate=5e-4, beta1=0.01)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    losses = []
+    for i in range(60):
+        sc = tr.step(H, Wd, focal, rays.to(DEV), target, t_rand=torch.rand(N, 128, device=DEV, generator=g),
+                     eps=torch.randn(4, 4, device=DEV, generator=g))
+        losses.append(float(sc[2]))                     # mse of the K-mean prediction
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 0.7 * np.mean(losses[:10]), (losses[:10], losses[-10:])
