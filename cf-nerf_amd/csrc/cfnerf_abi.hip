@@ -253,6 +253,33 @@ int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float*
     }
     return CFNERF_OK;
 }
+// copy a stash / backward-workspace buffer of the last STASH forward into dst (device), for tests
+int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s) {
+    if (!m || !m->stash.valid) return -1;
+    Stash& q = m->stash;
+    const int W = m->cfg.netwidth;
+    const int64_t P = q.N * (int64_t)q.S;
+    std::string n = name;
+    const float* src = nullptr; int64_t cnt = 0;
+    if (n == "h") { src = q.h + (size_t)layer * P * W; cnt = P * W; }
+    else if (n == "g_h") { src = q.g_h + (size_t)layer * P * W; cnt = P * W; }
+    else if (n == "feat") { src = q.feat; cnt = P * W; }
+    else if (n == "g_feat") { src = q.g_feat; cnt = P * W; }
+    else if (n == "v") { src = q.v; cnt = P * (W / 2); }
+    else if (n == "g_v") { src = q.g_v; cnt = P * (W / 2); }
+    else if (n == "ha") { src = q.ha; cnt = P * m->cfg.h_alpha_size; }
+    else if (n == "g_ha") { src = q.g_ha; cnt = P * m->cfg.h_alpha_size; }
+    else if (n == "hr") { src = q.hr; cnt = P * m->cfg.h_rgb_size; }
+    else if (n == "g_hr") { src = q.g_hr; cnt = P * m->cfg.h_rgb_size; }
+    else if (n == "theta") { src = q.theta; cnt = P * kThetaAll; }
+    else if (n == "g_theta") { src = q.g_theta; cnt = P * kThetaAll; }
+    else if (n == "enc") { src = q.enc; cnt = P * 64; }
+    else if (n == "at") { src = q.at; cnt = P * q.K * 2; }
+    else return -1;
+    if (cnt > max_floats) return -cnt;
+    if (hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) return -1;
+    return cnt;
+}
 // operand table entry by name: out[4] = {w_off, b_off, kc, nt}
 int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
