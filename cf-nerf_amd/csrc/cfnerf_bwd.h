@@ -41,22 +41,38 @@ struct DwTile {
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };
 
+// one workgroup of a weight-gradient launch: tile index, split slot and its point range
+struct DwBlock { int32_t tile, split, kslice, pad_; int64_t pb, pe; };
+
 struct BwdPlan {
     bool built = false;
     int nb = 0, db_h = 0, db_feat = 0, db_v = 0, db_ha = 0, db_hr = 0, db_theta = 0;
     std::vector<BiasMap> bias_maps;
     BiasMap* d_bias_maps = nullptr;
     float* d_dbp = nullptr; int dbp_wg = 0;
+    float* d_zeros = nullptr;                             // 256-B zero page for out-of-range operand fetches
     float* d_partials = nullptr; int partials_split = 0;
-    DwTile* d_tiles = nullptr; int n_tiles = 0;
+    DwTile *d_tiles = nullptr, *d_tiles_small = nullptr;
+    DwBlock *d_blocks = nullptr, *d_blocks_small = nullptr;
+    int n_blocks = 0, n_blocks_small = 0;
     const float* tiles_for = nullptr; int64_t tiles_P = 0;
     void release() {
-        if (d_bias_maps) hipFree(d_bias_maps);
-        if (d_dbp) hipFree(d_dbp);
-        if (d_partials) hipFree(d_partials);
-        if (d_tiles) hipFree(d_tiles);
-        d_bias_maps = nullptr; d_dbp = nullptr; d_partials = nullptr; d_tiles = nullptr;
-        dbp_wg = partials_split = n_tiles = 0; tiles_for = nullptr; tiles_P = 0;
+        if (d_bias_maps) (void)hipFree(d_bias_maps);
+        if (d_dbp) (void)hipFree(d_dbp);
+        if (d_zeros) (void)hipFree(d_zeros);
+        d_zeros = nullptr;
+        if (d_partials) (void)hipFree(d_partials);
+        release_tiles();
+        d_bias_maps = nullptr; d_dbp = nullptr; d_partials = nullptr;
+        dbp_wg = partials_split = 0;
+    }
+    void release_tiles() {
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (d_tiles_small) (void)hipFree(d_tiles_small);
+        if (d_blocks) (void)hipFree(d_blocks);
+        if (d_blocks_small) (void)hipFree(d_blocks_small);
+        d_tiles = d_tiles_small = nullptr; d_blocks = d_blocks_small = nullptr;
+        n_blocks = n_blocks_small = 0; tiles_for = nullptr; tiles_P = 0;
     }
 };
 

@@ -253,11 +253,41 @@ __host__ __device__ inline size_t bwd_lds_bytes(int W, int ha) {
     return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4));
 }
 
-// acc (+ ReLU mask from `mask` > 0) -> LDS tile, global dY matrix, per-workgroup bias partials
+// Epilogue operands fetched BEFORE the MFMA block of a layer so their HBM/L2 latency hides under it:
+// the ReLU mask (stashed activation > 0) of this lane's output fragment and the running bias partial.
 template <int NTW>
-__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], int nt_total, int nt0, int nts, float* lds_dst, int ld,
-                                          const float* __restrict__ mask, int mld, float* __restrict__ gdst, int gld,
-                                          float* __restrict__ dbp, int rows_valid) {
+struct EpiPre {
+    float mv[NTW][2][16];
+    float db[NTW];
+};
+
+template <int NTW>
+__device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int nt0, int nts, const float* __restrict__ mask, int mld,
+                                             const float* __restrict__ dbp, int rows_valid) {
+    const int lane = lane_id_opaque();
+    const int rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = nt0 + j * nts;
+        if (nt >= nt_total) nt = nt0 < nt_total ? nt0 : 0;      // clamped: value unused
+        const int col = nt * 32 + (lane & 31);
+        e.db[j] = dbp[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const int rc = min(rr + rbase, rows_valid - 1);      // unconditional, clamped into the tile
+                e.mv[j][i][r] = (mask != nullptr) ? ld_stream(mask + (size_t)rc * mld + col) : 1.f;
+            }
+    }
+}
+
+// acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials
+template <int NTW>
+__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                          int rows_valid) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -267,7 +297,6 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], int nt_to
         const int col = nt * 32 + (lane & 31);
         float* lp = lds_dst + rbase * ld + col;
         float* gp = gdst + (size_t)rbase * gld + col;
-        const float* mp = (mask != nullptr) ? mask + (size_t)rbase * mld + col : nullptr;
         float csum = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -275,14 +304,13 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], int nt_to
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const bool ok = rr + rbase < rows_valid;
-                float v = ok ? acc[i][j][r] : 0.f;
-                if (mp != nullptr && ok) v = (mp[(size_t)rr * mld] > 0.f) ? v : 0.f;
+                const float v = (ok && e.mv[j][i][r] > 0.f) ? acc[i][j][r] : 0.f;
                 lp[rr * ld] = v;
-                if (ok) gp[(size_t)rr * gld] = v;
+                if (ok) st_stream(gp + (size_t)rr * gld, v);
                 csum += v;
             }
         csum += __shfl_xor(csum, 32, 64);
-        if (lane < 32) dbp[col] += csum;          // this (workgroup, column) is owned by exactly one lane: no atomics
+        if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }
 }
 
@@ -321,53 +349,64 @@ void bwd_data_kernel(const BwdArgs A) {
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
         {
             f32x16 acc[2][1];
+            EpiPre<1> e;
             acc_zero(acc);
             const bool is_rgb = wave < 2;
-            if (is_rgb) mma_seg<1>(acc, T.bt_fr, wave, kWaves, wp, act, LD);
-            else        mma_seg<1>(acc, T.bt_fa, wave - 2, kWaves, wp, act + kThetaRgb, LD);
+            if (is_rgb) {
+                epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, 0, dbp + A.db_hr, rows_valid);
+                mma_seg<1>(acc, T.bt_fr, wave, kWaves, wp, act, LD);
+            } else {
+                epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, 0, dbp + A.db_ha, rows_valid);
+                mma_seg<1>(acc, T.bt_fa, wave - 2, kWaves, wp, act + kThetaRgb, LD);
+            }
             __syncthreads();
-            if (is_rgb) store_bwd<1>(acc, T.bt_fr.nt, wave, kWaves, act, LD, nullptr, 0, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
-            else        store_bwd<1>(acc, T.bt_fa.nt, wave - 2, kWaves, hs, HLD, nullptr, 0, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
+            if (is_rgb) store_bwd<1>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
+            else        store_bwd<1>(acc, e, T.bt_fa.nt, wave - 2, kWaves, hs, HLD, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
             __syncthreads();
         }
         // ---- 2. dv = (dh_rgb * R) . relu'(v)
         {
             f32x16 acc[2][NTV];
+            EpiPre<NTV> e;
             acc_zero(acc);
+            epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, A.st_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
             mma_seg<NTV>(acc, T.bt_hr, wave, kWaves, wp, act, LD);
             __syncthreads();
-            store_bwd<NTV>(acc, T.bt_hr.nt, wave, kWaves, act, LD, A.st_v + p0 * (W / 2), W / 2, A.g_v + p0 * (W / 2), W / 2,
-                           dbp + A.db_v, rows_valid);
+            store_bwd<NTV>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
             __syncthreads();
         }
         // ---- 3. dfeature = dv * V[:, 0:W]        (feature_linear has no activation, MOD:176)
         {
             f32x16 acc[2][NTW];
+            EpiPre<NTW> e;
             acc_zero(acc);
+            epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, 0, dbp + A.db_feat, rows_valid);
             mma_seg<NTW>(acc, T.bt_vf, wave, kWaves, wp, act, LD);
             __syncthreads();
-            store_bwd<NTW>(acc, T.bt_vf.nt, wave, kWaves, act, LD, nullptr, 0, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
+            store_bwd<NTW>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
             __syncthreads();
         }
         // ---- 4. dh_{D-1} = (dfeature * F + dh_alpha * A) . relu'(h_{D-1})
         {
             f32x16 acc[2][NTW];
+            EpiPre<NTW> e;
             acc_zero(acc);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, A.st_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
             mma_seg<NTW>(acc, T.bt_ft, wave, kWaves, wp, act, LD);
             mma_seg<NTW>(acc, T.bt_ha, wave, kWaves, wp, hs, HLD);
             __syncthreads();
-            store_bwd<NTW>(acc, NT, wave, kWaves, act, LD, A.st_h + ((size_t)(D - 1) * P + p0) * W, W,
-                           A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
+            store_bwd<NTW>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
             __syncthreads();
         }
         // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
         for (int l = D - 1; l >= 1; --l) {
             f32x16 acc[2][NTW];
+            EpiPre<NTW> e;
             acc_zero(acc);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, A.st_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             mma_seg<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD);
             __syncthreads();
-            store_bwd<NTW>(acc, NT, wave, kWaves, act, LD, A.st_h + ((size_t)(l - 1) * P + p0) * W, W,
-                           A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
+            store_bwd<NTW>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             __syncthreads();
         }
     }
@@ -375,25 +414,77 @@ void bwd_data_kernel(const BwdArgs A) {
 
 // ================================================================================================
 // 4. weight gradients: dW[n][k] = sum_p dY[p][n] X[p][k], fp32 MFMA, P split across workgroups.
-//    Workgroup tile 128 (n) x 256 (k): every wave owns 64 k-columns and all 128 rows (4 x 2 MFMA tiles).
-//    Operands come straight from global memory as 16-B / 8-B vectors: lane (i, kk) reads
-//    dY[p + kk][n0 + 4i .. 4i+3] and X[p + kk][k0 + 2i .. 2i+1]; MFMA tile t uses vector component t,
-//    i.e. the rows (cols) of a tile are interleaved with stride 4 (2) - a free relabelling.
-__global__ __launch_bounds__(kThreads, 2)
-void dw_kernel(const DwTile* __restrict__ tiles, int nsplit, int64_t P, int64_t p_chunk, float* __restrict__ partials,
-               int64_t n_params) {
-    const int lane = lane_id_opaque(), wave = wave_id();
-    const DwTile t = tiles[blockIdx.x / nsplit];
-    const int split = blockIdx.x % nsplit;
-    const int kw0 = t.k0 + 64 * wave;
-    if (kw0 >= t.K) return;
-    const int64_t pb = (int64_t)split * p_chunk, pe = min(P, pb + p_chunk);
-    const int i = lane & 31, kk = lane >> 5;
-    const int ncol = t.n0 + 4 * i, kcol = kw0 + 2 * i;
-    const bool n_ok = ncol + 4 <= t.Npad;          // the 16-B vector stays inside the readable part of the dY row
-    const bool k_ok = kcol + 2 <= t.Kpad;
-    const float* yp = t.dY + ncol;
-    const float* xp = t.X + kcol;
+//    MFMA tile t of a wave uses vector component t of its operand vectors, i.e. the rows (cols) of a
+//    tile are interleaved with stride 4 (2): lane (i, kk) holds dY[p + kk][n + 4i .. 4i+3] and
+//    X[p + kk][k + 2i .. 2i+1] - a free relabelling that makes every operand fetch a full 16-B / 8-B vector.
+typedef const float __attribute__((address_space(1)))* gcf_ptr;      // explicit global address space: the pointers
+typedef float __attribute__((address_space(1)))* gf_ptr;             // come out of a struct in memory (else flat_load)
+
+__device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const f32x16 (&acc)[4][2], int n_base, int k_base, int lane) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+            const int k = k_base + 2 * (lane & 31) + tk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n_base + 4 * frag_row(r, lane) + tn;
+                if (n < t.N && k < t.K) {
+                    int sg = 0;
+                    if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
+                    if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
+                    if (t.nseg > 3 && n >= t.seg_row[3]) sg = 3;
+                    const uint32_t dst = sg == 0 ? t.seg_dst[0] : sg == 1 ? t.seg_dst[1] : sg == 2 ? t.seg_dst[2] : t.seg_dst[3];
+                    const int row0 = sg == 0 ? t.seg_row[0] : sg == 1 ? t.seg_row[1] : sg == 2 ? t.seg_row[2] : t.seg_row[3];
+                    out[(size_t)dst + (size_t)(n - row0) * t.dst_ld + t.dst_col + k] = acc[tn][tk][r];
+                }
+            }
+        }
+}
+
+// ---- 4a. big tiles (256 x 256 per workgroup, 8 waves = 2 (n) x 4 (k), each 128 x 64): operands are staged
+//      through double-buffered LDS (32 points per stage) with register prefetch, so every dY / X element is
+//      read from HBM exactly once and the loads of stage s+1 fly under the 128 MFMAs per wave of stage s.
+constexpr int kDwRows = 32;                   // points per LDS stage
+constexpr int kDwSmallGroup = 5;              // dw_small_kernel: point-pairs per register group (2 groups in flight)
+constexpr int kDwThreads = 512;
+__global__ __launch_bounds__(kDwThreads, 2)
+void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
+                   const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                 // [2][32][256]
+    float* Bs = smem + 2 * kDwRows * 256;             // [2][32][256]
+    const DwBlock blk = blocks[blockIdx.x];
+    const DwTile t = tiles[blk.tile];
+    const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
+    const int wn = wave >> 2, wk = wave & 3;
+    const int64_t pb = blk.pb, pe = blk.pe;
+    gcf_ptr gy = (gcf_ptr)t.dY, gx = (gcf_ptr)t.X;
+    // loader geometry: thread -> (row = tid / 64 + 8 * pass, 16-B column c = tid % 64)
+    const int lrow = tid >> 6, lc = tid & 63;
+    const bool a_col_ok = t.n0 + 4 * lc + 4 <= t.Npad, b_col_ok = t.k0 + 4 * lc + 4 <= t.Kpad;
+    const int a_col = a_col_ok ? t.n0 + 4 * lc : 0, b_col = b_col_ok ? t.k0 + 4 * lc : 0;
+    // Invalid elements (rows past the slab, columns past the matrix) are fetched from a zero page: the select is on
+    // the ADDRESS, so nothing consumes the loaded registers until the LDS store after the MFMA block.
+    gcf_ptr zp = (gcf_ptr)zeros;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int64_t p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t pr = p + lrow + 8 * q;
+            gcf_ptr pa = (pr < pe && a_col_ok) ? gy + pr * t.ldY + a_col : zp;
+            gcf_ptr pbk = (pr < pe && b_col_ok) ? gx + pr * t.ldX + b_col : zp;
+            ra[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
+            rb[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pbk);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(As + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc)) = ra[q];
+            *reinterpret_cast<f32x4*>(Bs + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc)) = rb[q];
+        }
+    };
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -401,48 +492,102 @@ void dw_kernel(const DwTile* __restrict__ tiles, int nsplit, int64_t P, int64_t 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool active = (t.n0 + 128 * wn < t.N) && (t.k0 + 64 * wk < t.K);     // wave-uniform
+    const int i = lane & 31, kk = lane >> 5;
+    const float* a_rd = As + kk * 256 + 128 * wn + 4 * i;
+    const float* b_rd = Bs + kk * 256 + 64 * wk + 2 * i;
 
-    auto load = [&](int64_t p, f32x4& av, f32x2& bv) {
-        const int64_t pr = p + kk;
-        av[0] = av[1] = av[2] = av[3] = 0.f; bv[0] = bv[1] = 0.f;
-        if (pr < pe) {
-            if (n_ok) av = *reinterpret_cast<const f32x4*>(yp + pr * t.ldY);
-            if (k_ok) bv = *reinterpret_cast<const f32x2*>(xp + pr * t.ldX);
-        }
-    };
-    f32x4 a0, a1, a2, a3; f32x2 b0, b1, b2, b3;
-    int64_t p = pb;
-    load(p, a0, b0); load(p + 2, a1, b1);
-    for (; p < pe; p += 8) {
-        load(p + 4, a2, b2); load(p + 6, a3, b3);
+    gload(pb);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t p = pb; p < pe; p += kDwRows) {
+        const bool more = p + kDwRows < pe;
+        if (more) gload(p + kDwRows);
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
+        if (active) {
+            const float* ar = a_rd + buf * kDwRows * 256;
+            const float* br = b_rd + buf * kDwRows * 256;
+#pragma unroll 4
+            for (int pp = 0; pp < kDwRows / 2; ++pp) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
+                const f32x2 bv = *reinterpret_cast<const f32x2*>(br + pp * 512);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a0[tn], b0[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a0[tn], b0[1], acc[tn][1]); }
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a1[tn], b1[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a1[tn], b1[1], acc[tn][1]); }
-        load(p + 8, a0, b0); load(p + 10, a1, b1);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a2[tn], b2[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a2[tn], b2[1], acc[tn][1]); }
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(a3[tn], b3[0], acc[tn][0]); acc[tn][1] = CFN_MFMA(a3[tn], b3[1], acc[tn][1]); }
-    }
-    // ---- write this split's partial tile in the flat gradient layout
-    float* out = partials + (size_t)split * n_params;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int tk = 0; tk < 2; ++tk) {
-            const int k = kw0 + 2 * (lane & 31) + tk;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = t.n0 + 4 * frag_row(r, lane) + tn;
-                if (n < t.N && k < t.K) {
-                    int sg = 0;
-#pragma unroll
-                    for (int q = 1; q < 4; ++q) if (q < t.nseg && n >= t.seg_row[q]) sg = q;
-                    out[(size_t)t.seg_dst[sg] + (size_t)(n - t.seg_row[sg]) * t.dst_ld + t.dst_col + k] = acc[tn][tk][r];
+                for (int tn = 0; tn < 4; ++tn) {
+                    acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
+                    acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (active)
+        dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
+}
+
+// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads): ONE WAVE per block computes a
+//      128 (n) x 64 (k) tile of one split, operands straight from global memory with a deep register pipeline.
+//      Wave-granular blocks: only k-slices that exist are launched and ~8 of them fit per CU.
+__global__ __launch_bounds__(64, 2)
+void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
+                     const float* __restrict__ zeros) {
+    const int lane = lane_id_opaque();
+    const DwBlock blk = blocks[blockIdx.x];
+    const DwTile t = tiles[blk.tile];
+    const int kw0 = t.k0 + 64 * blk.kslice;
+    if (kw0 >= t.K) return;
+    const int64_t pb = blk.pb, pe = blk.pe;
+    const int i = lane & 31, kk = lane >> 5;
+    const int ncol = t.n0 + 4 * i, kcol = kw0 + 2 * i;
+    const bool n_ok = ncol + 4 <= t.Npad;          // the 16-B vector stays inside the readable part of the dY row
+    const bool k_ok = kcol + 2 <= t.Kpad;
+    gcf_ptr yq = (gcf_ptr)t.dY + ncol;
+    gcf_ptr xq = (gcf_ptr)t.X + kcol;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    gcf_ptr zp = (gcf_ptr)zeros;
+    // unconditional loads; invalid rows / columns read a zero page (address select, nothing consumes the data early)
+    auto load = [&](int64_t p, f32x4& av, f32x2& bv) {
+        const int64_t pr = p + kk;
+        gcf_ptr pa = (pr < pe && n_ok) ? yq + pr * t.ldY : zp;
+        gcf_ptr pb_ = (pr < pe && k_ok) ? xq + pr * t.ldX : zp;
+        av = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
+        bv = *reinterpret_cast<const f32x2 __attribute__((address_space(1)))*>(pb_);
+    };
+    // two register groups of 8 point-pairs each: the loads of group g+1 (16 vectors per lane) are in flight
+    // under the 64 MFMAs (~4k cycles) of group g - operands come straight from HBM, latency ~2 us
+    constexpr int G = kDwSmallGroup;             // point-pairs per register group
+    f32x4 ga[G], ha[G]; f32x2 gb[G], hb[G];
+    int64_t p = pb;
+#pragma unroll
+    for (int q = 0; q < G; ++q) load(p + 2 * q, ga[q], gb[q]);
+    for (; p < pe; p += 4 * G) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) load(p + 2 * G + 2 * q, ha[q], hb[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(ga[q][tn], gb[q][0], acc[tn][0]); acc[tn][1] = CFN_MFMA(ga[q][tn], gb[q][1], acc[tn][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < G; ++q) load(p + 4 * G + 2 * q, ga[q], gb[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(ha[q][tn], hb[q][0], acc[tn][0]); acc[tn][1] = CFN_MFMA(ha[q][tn], hb[q][1], acc[tn][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0, kw0, lane);
 }
 
 // ================================================================================================
@@ -455,16 +600,22 @@ __global__ void reduce_weights_kernel(const float* __restrict__ partials, int ns
     grad[i] = s;
 }
 
-__global__ void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const BiasMap* __restrict__ maps, int n_maps,
-                                   float* __restrict__ grad) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;      // column of the bias partial table
-    if (j >= nb) return;
-    int m = -1;
-    for (int q = 0; q < n_maps; ++q) if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) m = q;
-    if (m < 0) return;
+__global__ __launch_bounds__(256)
+void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const BiasMap* __restrict__ maps, int n_maps,
+                        float* __restrict__ grad) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;                     // column of the bias partial table
     float s = 0.f;
-    for (int w = 0; w < n_wg; ++w) s += dbp[(size_t)w * nb + j];
-    grad[maps[m].dst + (j - maps[m].col0)] = s;
+    if (j < nb)
+        for (int w = part; w < n_wg; w += 4) s += dbp[(size_t)w * nb + j];      // coalesced across the 64 lanes
+    sh[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && j < nb) {
+        const float tot = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        for (int q = 0; q < n_maps; ++q)
+            if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) grad[maps[q].dst + (j - maps[q].col0)] = tot;
+    }
 }
 
 // base-Gaussian parameters: chain through z0 = eps*std + mean (tail partials) + d mean(base log-normal)/d std = -1/std
@@ -591,18 +742,35 @@ static int ensure_bwd_plan(cfnerf_model* m) {
     return 0;
 }
 
-// one weight-gradient job -> tiles of 128 x 256
-static void add_job(std::vector<DwTile>& tiles, const float* dY, int ldY, int Nread, int N, const float* X, int ldX, int K, int Kvalid,
-                    int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
-    for (int n0 = 0; n0 < N; n0 += 128)
+// one weight-gradient job -> tiles: 256 x 256 ("big": LDS-staged kernel) when the job is at least 128 x 128,
+// else 128 x 256 ("small": direct-load kernel)
+static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const float* dY, int ldY, int Nread, int N, const float* X,
+                    int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
+    const bool is_big = N >= 128 && Kvalid >= 128;
+    const int tn = is_big ? 256 : 128;
+    for (int n0 = 0; n0 < N; n0 += tn)
         for (int k0 = 0; k0 < Kvalid; k0 += 256) {
             DwTile t{};
             t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
             t.nseg = nseg;
             for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
             t.dst_ld = dst_ld; t.dst_col = dst_col;
-            tiles.push_back(t);
+            (is_big ? big : small).push_back(t);
         }
+}
+
+// per_kslice: one block per existing 64-wide k-slice of every tile (small kernel), else one block per tile
+static void make_blocks(std::vector<DwBlock>& blocks, const std::vector<DwTile>& tiles, int nsplit, int64_t P, int round_to, bool per_kslice) {
+    int64_t chunk = (P + nsplit - 1) / nsplit;
+    chunk = (chunk + round_to - 1) / round_to * round_to;
+    for (int s = 0; s < nsplit; ++s) {
+        const int64_t pb = (int64_t)s * chunk, pe = std::min<int64_t>(P, pb + chunk);
+        if (pb >= pe) continue;
+        for (int t = 0; t < (int)tiles.size(); ++t) {
+            const int nks = per_kslice ? std::min(4, (tiles[t].K - tiles[t].k0 + 63) / 64) : 1;
+            for (int ks = 0; ks < nks; ++ks) { DwBlock b; b.tile = t; b.split = s; b.kslice = ks; b.pb = pb; b.pe = pe; blocks.push_back(b); }
+        }
+    }
 }
 
 extern "C" {
@@ -635,20 +803,19 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
 
     // ---- workspace sizes that depend on the batch
     const int n_wg = m->n_cu * ((W <= 256) ? 2 : 1);
-    int nsplit = 16;
-    while (nsplit > 1 && P / nsplit < 1024) nsplit >>= 1;
-    int64_t p_chunk = (P + nsplit - 1) / nsplit;
-    p_chunk = (p_chunk + 7) / 8 * 8;
+    const int kMaxSplit = 64;
     if (B.dbp_wg < n_wg || !B.d_dbp) {
         if (B.d_dbp) hipFree(B.d_dbp);
         BHIP(hipMalloc(&B.d_dbp, (size_t)n_wg * B.nb * sizeof(float)));
         B.dbp_wg = n_wg;
     }
-    if (B.partials_split < nsplit || !B.d_partials) {
-        if (B.d_partials) hipFree(B.d_partials);
-        BHIP(hipMalloc(&B.d_partials, (size_t)nsplit * n_params * sizeof(float)));
-        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)nsplit * n_params * sizeof(float), st));   // bias/dead slots stay 0 forever
-        B.partials_split = nsplit;
+    if (!B.d_partials) {
+        BHIP(hipMalloc(&B.d_partials, (size_t)kMaxSplit * n_params * sizeof(float)));
+        B.partials_split = kMaxSplit;
+    }
+    if (!B.d_zeros) {
+        BHIP(hipMalloc(&B.d_zeros, 256));
+        BHIP(hipMemsetAsync(B.d_zeros, 0, 256, st));
     }
     if (!B.d_bias_maps) {
         BHIP(hipMalloc(&B.d_bias_maps, B.bias_maps.size() * sizeof(BiasMap)));
@@ -656,7 +823,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     }
     // ---- weight-gradient tile list (pointers depend on the stash allocation)
     if (B.tiles_for != q.h || B.tiles_P != P) {
-        std::vector<DwTile> tiles;
+        std::vector<DwTile> big, small;
         char key[64];
         const int one_row[1] = {0};
         for (int l = 0; l < D; ++l) {
@@ -664,41 +831,65 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
             const uint32_t dst[1] = {(uint32_t)L.off(key)};
             const float* dY = q.g_h + (size_t)l * P * W;
             if (l == 0) {
-                add_job(tiles, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
+                add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
             } else if (l - 1 == skip) {
-                add_job(tiles, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
-                add_job(tiles, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
+                add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
+                add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
             } else {
-                add_job(tiles, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
+                add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
             }
         }
         const float* hlast = q.h + (size_t)(D - 1) * P * W;
-        { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(tiles, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
-        { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(tiles, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
+        { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
+        { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
         {
             const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
-            add_job(tiles, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
-            add_job(tiles, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
+            add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
+            add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
         }
-        { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(tiles, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
+        { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
         {
             const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
             const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
                                      (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
-            add_job(tiles, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
+            add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
         }
         {
             const int rows[3] = {0, F, 2 * F};
             const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
                                      (uint32_t)L.off("flows_alpha.amor_b.weight")};
-            add_job(tiles, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
+            add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
         }
-        if (B.d_tiles) hipFree(B.d_tiles);
-        BHIP(hipMalloc(&B.d_tiles, tiles.size() * sizeof(DwTile)));
-        BHIP(hipMemcpyAsync(B.d_tiles, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
-        BHIP(hipStreamSynchronize(st));       // `tiles` is a host temporary
-        B.n_tiles = (int)tiles.size();
+        // split counts: every block of a kernel gets the same number of points; big tiles ~1 block per CU in total,
+        // small jobs a finer split (their blocks are short and run several per CU)
+        int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, big.size())));
+        ns_big = std::min(ns_big, kMaxSplit);
+        while (ns_big > 1 && P / ns_big < 512) --ns_big;
+        int ns_small = kMaxSplit;
+        while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
+        std::vector<DwBlock> bb, sb;
+        make_blocks(bb, big, ns_big, P, kDwRows, false);
+        make_blocks(sb, small, ns_small, P, 4 * kDwSmallGroup, true);
+        B.release_tiles();
+        BHIP(hipMalloc(&B.d_tiles, std::max<size_t>(1, big.size()) * sizeof(DwTile)));
+        BHIP(hipMalloc(&B.d_tiles_small, std::max<size_t>(1, small.size()) * sizeof(DwTile)));
+        BHIP(hipMalloc(&B.d_blocks, std::max<size_t>(1, bb.size()) * sizeof(DwBlock)));
+        BHIP(hipMalloc(&B.d_blocks_small, std::max<size_t>(1, sb.size()) * sizeof(DwBlock)));
+        BHIP(hipMemcpyAsync(B.d_tiles, big.data(), big.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
+        BHIP(hipMemcpyAsync(B.d_tiles_small, small.data(), small.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
+        BHIP(hipMemcpyAsync(B.d_blocks, bb.data(), bb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
+        BHIP(hipMemcpyAsync(B.d_blocks_small, sb.data(), sb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
+        // split slots a tile does not write must read as zero in the reduction
+        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)kMaxSplit * n_params * sizeof(float), st));
+        BHIP(hipStreamSynchronize(st));       // the vectors are host temporaries
+        B.n_blocks = (int)bb.size(); B.n_blocks_small = (int)sb.size();
         B.tiles_for = q.h; B.tiles_P = P;
+        static bool attr_set = false;
+        if (!attr_set) {
+            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(4 * kDwRows * 256 * sizeof(float))));
+            attr_set = true;
+        }
     }
 
     // ---- 1. tail
@@ -725,13 +916,20 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
 
     // ---- 3. weight gradients + reductions
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
-    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)(B.n_tiles * nsplit)), dim3(kThreads), 0, st, B.d_tiles, nsplit, P, p_chunk,
-                       B.d_partials, n_params);
-    BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, nsplit,
+    if (B.n_blocks > 0) {
+        hipLaunchKernelGGL(dw_big_kernel, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
+                           B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
+        BHIP(hipGetLastError());
+    }
+    if (B.n_blocks_small > 0) {
+        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(64), 0, st, B.d_tiles_small, B.d_blocks_small,
+                           B.d_partials, n_params, B.d_zeros);
+        BHIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, kMaxSplit,
                        n_params, grad_flat);
     BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 255) / 256)), dim3(256), 0, st, B.d_dbp, grid_bd, B.nb,
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(256), 0, st, B.d_dbp, grid_bd, B.nb,
                        B.d_bias_maps, (int)B.bias_maps.size(), grad_flat);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N, m->flat, d_entropy, grad_flat);

@@ -107,6 +107,10 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int
     if (NTW > 3 && nvalid == 3) { mma_loop<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
 }
 
+// streaming (touch-once) global traffic: keep it from evicting the L2-resident packed weights
+__device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -136,7 +140,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
                 float v = acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                 lp[rr * ld] = v;
-                if (gp != nullptr && rr + rbase < rows_valid) gp[rr * gld] = v;
+                if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * gld, v);
             }
     }
 }

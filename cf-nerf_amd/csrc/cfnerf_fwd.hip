@@ -139,7 +139,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
                     const int row = idx >> 6, c = idx & 63;
-                    if (row < rows_valid) A.st_enc[(p0 + row) * 64 + c] = act[row * LD + c];
+                    if (row < rows_valid) st_stream(A.st_enc + (p0 + row) * 64 + c, act[row * LD + c]);
                 }
             }
             __syncthreads();
@@ -187,7 +187,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     if (MODE == 0) v = gdir[c];
                     else v = (c < icv && row < rows_valid) ? A.x[(p0 + row) * (int64_t)(ic + icv) + ic + c] : 0.f;
                     act[row * LD + c] = v;
-                    if (A.st_gd != nullptr && row < rows_valid) A.st_gd[(p0 + row) * 32 + c] = v;
+                    if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
                 mma_seg<C::NTV>(acc, T.vd, wave, kWaves, wp, act, LD);
@@ -234,7 +234,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                         float v = acc[i][0][r] + bv;
                         if (tanh_col) v = tanhf(v);                   // diag_activation, MOD:337-348
                         lp[rr * LD] = v;
-                        if (gp != nullptr && rr + rbase < rows_valid) gp[rr * kThetaAll] = v;
+                        if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * kThetaAll, v);
                     }
                 __syncthreads();
             }
