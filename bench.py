@@ -107,9 +107,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("CFNERF_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (tests)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if force_dist and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     import cfnerf_amd
@@ -134,7 +138,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234)           # same latent samples on every rank
 
     if mode == "train":
-        trainer = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world)
+        trainer = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist)
 
     def step():
         t_rand = torch.rand(N_RAND, S, device=dev)
@@ -145,7 +149,7 @@ def main():
             return cfnerf_amd.render(H, Wd, focal, rays=rays, **kw_test)
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +169,7 @@ def main():
     if mode == "train":
         for name, idx in (("bwd_tail", 1), ("bwd_data", 2), ("bwd_dw", 3), ("adam", 4)):
             extra_ms[name] = lib.cfnerf_timing_last_ms(net.handle, idx)
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -192,7 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

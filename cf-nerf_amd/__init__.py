@@ -3,6 +3,7 @@
 Import as ``import cfnerf_amd`` (repo-root shim; the directory name ``cf-nerf_amd`` is not an identifier).
 """
 from . import _lib  # noqa: F401
+from . import train  # noqa: F401
 from .api import (Embedder, NeRF_Flows, batchify, batchify_rays, create_nerf, get_embedder, get_rays, img2mse,  # noqa: F401
                   mse2psnr, ndc_rays, param_layout, raw2outputs, render, render_rays, run_network, t_vals_table)
 

@@ -41,15 +41,16 @@ def lr_at(lrate: float, lrate_decay: int, start: int, t: int) -> float:
     return lrate * (0.1 ** ((start + t - 1) / (lrate_decay * 1000)))
 
 
-def allreduce_sum_(grad: torch.Tensor, world: int, group=None):
-    if world > 1:
+def allreduce_sum_(grad: torch.Tensor, world: int, group=None, force: bool = False):
+    if world > 1 or force:
         import torch.distributed as dist
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
 
 
 class Trainer:
-    def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0):
+    def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False):
+        self.force_allreduce = bool(force_allreduce)
         self.net: NeRF_Flows = _unwrap(net)
         dev = self.net.flat.device
         self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
@@ -115,7 +116,7 @@ class Trainer:
         """One full train step.  Returns the device tensor [loss, loss_nll, mse, psnr] of the local shard."""
         kw = {k: v for k, v in kw.items() if k in ("t_rand", "eps", "near", "far", "ndc", "lindisp", "white_bkgd", "perturb", "t_vals")}
         self.forward_backward(H, W, focal, rays, target, **kw)
-        allreduce_sum_(self.grad, self.world, self.group)
+        allreduce_sum_(self.grad, self.world, self.group, self.force_allreduce)
         lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
         self.t += 1
         net = self.net
