@@ -408,7 +408,7 @@ class _RenderFn(torch.autograd.Function):
         ent = torch.zeros(1, device=dev)
         L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K,
                                           flags | L.F_STASH, L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), None,
-                                          L.ptr(pts), L.ptr(ent), L.stream()), "cfnerf_render_fwd")
+                                          L.ptr(pts), None, L.ptr(ent), L.stream()), "cfnerf_render_fwd")
         ctx.model = model
         ctx.n_params = flat.numel()
         ctx.mark_non_differentiable(disp, raw)
@@ -489,7 +489,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
     wts = torch.empty(N, S, K, device=dev) if retweights else None
     ent = torch.zeros(1, device=dev)
     L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K, flags,
-                                      L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), L.ptr(wts), L.ptr(pts), L.ptr(ent),
+                                      L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), L.ptr(wts), L.ptr(pts), None, L.ptr(ent),
                                       L.stream()), "cfnerf_render_fwd")
     ret = {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth}
     if is_train:
@@ -553,15 +553,15 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         packed = torch.empty(N, 11, device=dev)
         arr = (C.c_float * 12)(*c2w_t.reshape(-1).tolist())
         if c2w_staticcam is None:
-            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, int(bool(ndc)), float(near), float(far),
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, int(bool(ndc)), float(near), float(far),
                                           L.ptr(packed), L.stream()), "cfnerf_rays_setup")
         else:   # RUN:139-141: view directions from c2w, geometry from the static camera
-            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, float(near), float(far), L.ptr(packed),
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, 0, float(near), float(far), L.ptr(packed),
                                           L.stream()), "cfnerf_rays_setup")
             vd = packed[:, 8:11].clone()
             sc = torch.as_tensor(c2w_staticcam, dtype=torch.float32).cpu()[:3, :4].contiguous()
             arr2 = (C.c_float * 12)(*sc.reshape(-1).tolist())
-            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr2, None, None, N, int(bool(ndc)), float(near), float(far),
+            L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr2, None, None, N, 0, int(bool(ndc)), float(near), float(far),
                                           L.ptr(packed), L.stream()), "cfnerf_rays_setup")
             packed[:, 8:11] = vd
     else:
@@ -572,7 +572,7 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         N = rd.shape[0]
         packed = torch.empty(N, 11, device=rd.device)
         nf, ff = (near if not torch.is_tensor(near) else 0.), (far if not torch.is_tensor(far) else 1.)
-        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, int(bool(ndc)), float(nf), float(ff),
+        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, 0, int(bool(ndc)), float(nf), float(ff),
                                       L.ptr(packed), L.stream()), "cfnerf_rays_setup")
         if torch.is_tensor(near):
             packed[:, 6] = near.reshape(-1).to(packed)

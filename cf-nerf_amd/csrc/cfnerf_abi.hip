@@ -122,17 +122,18 @@ int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_st
 }
 
 int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host, const float* rays_o, const float* rays_d,
-                      int64_t N, int ndc, float near_, float far_, float* rays, cfnerf_stream s) {
+                      int64_t N, int64_t pixel0, int ndc, float near_, float far_, float* rays, cfnerf_stream s) {
     if (!rays || N < 0) return fail(CFNERF_E_INVALID, "bad rays/N");
     if (N == 0) return CFNERF_OK;
     RaysC2W c{};
     if (c2w_host) {
-        if (N != (int64_t)H * W) return fail(CFNERF_E_INVALID, "c2w given: N (%lld) must equal H*W (%lld)", (long long)N, (long long)H * W);
+        if (pixel0 < 0 || pixel0 + N > (int64_t)H * W)
+            return fail(CFNERF_E_INVALID, "c2w given: pixels [%lld, %lld) exceed H*W = %lld", (long long)pixel0, (long long)(pixel0 + N), (long long)H * W);
         std::memcpy(c.m, c2w_host, sizeof c.m);
     } else if (!rays_o || !rays_d) {
         return fail(CFNERF_E_INVALID, "either c2w_host or rays_o/rays_d must be given");
     }
-    HIPCHK(launch_rays_setup(H, W, focal, c, c2w_host ? 1 : 0, rays_o, rays_d, N, ndc, near_, far_, rays, (hipStream_t)s));
+    HIPCHK(launch_rays_setup(H, W, focal, c, c2w_host ? 1 : 0, rays_o, rays_d, N, pixel0, ndc, near_, far_, rays, (hipStream_t)s));
     return CFNERF_OK;
 }
 
@@ -145,11 +146,15 @@ static int check_common(cfnerf_model* m, int K) {
 
 int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand, const float* eps,
                       int64_t N, int S, int K, int flags, float* rgb_map, float* disp_map, float* depth_map,
-                      float* raw_opt, float* weights_opt, float* pts_opt, float* entropy_out, cfnerf_stream s) {
+                      float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out, cfnerf_stream s) {
     if (int rc = check_common(m, K)) return rc;
     if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
     if (N == 0) return CFNERF_OK;            // empty batch: nothing to do (buffers may be NULL)
-    if (!rays || !t_vals || !eps || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (!rays || !t_vals || !eps) return fail(CFNERF_E_INVALID, "NULL argument");
+    const bool maps = rgb_map && disp_map && depth_map;
+    if (!maps && (rgb_map || disp_map || depth_map)) return fail(CFNERF_E_INVALID, "rgb_map/disp_map/depth_map must be given together");
+    if (!maps && !kstats_opt) return fail(CFNERF_E_INVALID, "either the per-K maps or kstats_opt must be requested");
+    if (kstats_opt && K < 2) return fail(CFNERF_E_INVALID, "kstats needs K >= 2 (std * n/(n-1))");
     hipStream_t st = (hipStream_t)s;
     if (flags & CFNERF_F_STASH) flags |= CFNERF_F_TRAIN;
     const bool train = flags & CFNERF_F_TRAIN;
@@ -159,8 +164,9 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     a.rays = rays; a.t_vals = t_vals; a.t_rand = t_rand; a.eps = eps;
     a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
-    a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt;
+    a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt; a.kstats = kstats_opt;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
+    if ((flags & CFNERF_F_STASH) && !maps) return fail(CFNERF_E_INVALID, "STASH needs the per-K maps");
     if (flags & CFNERF_F_STASH) {
         if (int rc = m->stash.ensure(m->cfg, N, S, K)) return fail(rc, "stash allocation failed (%lld points)", (long long)a.P);
         Stash& q = m->stash;

@@ -308,16 +308,38 @@ void fused_fwd_kernel(const FwdArgs A) {
         }  // chunks
 
         if (MODE == 0 && tid < K) {
-            const float* cp = comp + tid * 8;
+            float* cp = comp + tid * 8;
             const int k = tid;
             float r0 = cp[0], r1 = cp[1], r2 = cp[2];
             const float depth = cp[3], acc = cp[4];
             if (A.flags & CFNERF_F_WHITE_BKGD) { r0 = r0 + (1.f - acc); r1 = r1 + (1.f - acc); r2 = r2 + (1.f - acc); }  // RUN:451-452
             const float disp = 1.f / fmaxf(1e-10f + 1e-10f, depth / (acc + 1e-10f) + 1e-10f);                    // RUN:448
-            float* o = A.rgb_map + unit * 3 * (int64_t)K;
-            o[0 * K + k] = r0; o[1 * K + k] = r1; o[2 * K + k] = r2;                                               // [N,3,K] RUN:445
-            A.disp[unit * (int64_t)K + k] = disp;
-            A.depth[unit * (int64_t)K + k] = depth;
+            if (A.rgb_map != nullptr) {
+                float* o = A.rgb_map + unit * 3 * (int64_t)K;
+                o[0 * K + k] = r0; o[1 * K + k] = r1; o[2 * K + k] = r2;                                           // [N,3,K] RUN:445
+                A.disp[unit * (int64_t)K + k] = disp;
+                A.depth[unit * (int64_t)K + k] = depth;
+            }
+            cp[0] = r0; cp[1] = r1; cp[2] = r2; cp[6] = disp;
+        }
+        if (MODE == 0 && A.kstats != nullptr) {
+            // fused reductions over the K latent samples (RUN:1122-1131): mean, np.std * n/(n-1)
+            __syncthreads();
+            if (tid < 5) {
+                const int c = (tid < 3) ? tid : (tid == 3 ? 6 : 3);       // r, g, b, disp, depth slots of comp[k]
+                float mean = 0.f;
+                for (int k = 0; k < K; ++k) mean += comp[k * 8 + c];
+                mean /= (float)K;
+                float* o = A.kstats + unit * 8;
+                if (tid < 3) {
+                    float var = 0.f;
+                    for (int k = 0; k < K; ++k) { const float d = comp[k * 8 + c] - mean; var += d * d; }
+                    o[tid] = mean;
+                    o[3 + tid] = sqrtf(var / (float)K) * (float)K / (float)(K - 1);
+                } else {
+                    o[6 + (tid - 3)] = mean;
+                }
+            }
         }
         __syncthreads();
     }  // units
@@ -416,12 +438,13 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
 // ---------------------------------------------------------------------------------------------
 // ray set-up (render() RUN:129-158; get_rays HLP:288-297; ndc_rays HLP:360-377)
 __global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int use_c2w, const float* rays_o,
-                                  const float* rays_d, int64_t N, int ndc, float nearv, float farv, float* out) {
+                                  const float* rays_d, int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float o[3], d[3];
     if (use_c2w) {
-        const int j = (int)(n / Wd), i = (int)(n - (int64_t)j * Wd);                 // row-major pixels, i = x (HLP:289-291)
+        const int64_t pix = pixel0 + n;
+        const int j = (int)(pix / Wd), i = (int)(pix - (int64_t)j * Wd);             // row-major pixels, i = x (HLP:289-291)
         const float dir[3] = {((float)i - (float)Wd * .5f) / focal, -((float)j - (float)H * .5f) / focal, -1.f};   // HLP:292
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -532,9 +555,9 @@ hipError_t launch_composite(const float* raw, const float* z, const float* d, in
 }
 
 hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
-                             int64_t N, int ndc, float nearv, float farv, float* out, hipStream_t st) {
+                             int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out, hipStream_t st) {
     const int grid = (int)((N + 255) / 256);
-    hipLaunchKernelGGL(rays_setup_kernel, dim3(grid), dim3(256), 0, st, H, Wd, focal, c2w, use_c2w, ro, rd, N, ndc, nearv, farv, out);
+    hipLaunchKernelGGL(rays_setup_kernel, dim3(grid), dim3(256), 0, st, H, Wd, focal, c2w, use_c2w, ro, rd, N, pixel0, ndc, nearv, farv, out);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ struct FwdArgs {
     int32_t S, K, flags;
     float *rgb_map, *disp, *depth;       // [N,3,K] [N,K] [N,K]
     float *raw, *weights, *pts;          // optional [P,K,4] [P,K] [P,3]
+    float *kstats;                       // optional [N,8] fused K-statistics
     float* ent_partials;                 // [grid,2]  (TRAIN)
     // activation stash for the backward pass (all optional, row-major per point)
     float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
@@ -37,7 +38,7 @@ hipError_t launch_entropy_finalize(const float* partials, int n_part, const floa
 hipError_t launch_composite(const float* raw, const float* z, const float* d, int64_t N, int S, int K, int wb,
                             float* rgb, float* disp, float* depth, float* weights, hipStream_t st);
 hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
-                             int64_t N, int ndc, float nearv, float farv, float* out, hipStream_t st);
+                             int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out, hipStream_t st);
 hipError_t launch_pack(const float* flat, float* packed, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
 
 }  // namespace cfnerf

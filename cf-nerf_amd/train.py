@@ -91,7 +91,7 @@ class Trainer:
         S = t_vals.shape[0]
         self._buffers(N, K)
         st = L.stream()
-        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, int(bool(ndc)), float(near), float(far),
+        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, 0, int(bool(ndc)), float(near), float(far),
                                       L.ptr(self.packed), st), "cfnerf_rays_setup")
         if perturb > 0. and t_rand is None:
             t_rand = torch.rand(N, S, device=dev)
@@ -104,7 +104,7 @@ class Trainer:
         flags = L.F_STASH | L.F_TRAIN | (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0)
         L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(_f32c(t_rand) if t_rand is not None else None),
                                       L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
-                                      None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
+                                      None, None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
         L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
                                         C.c_float(self.beta1), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
                 "cfnerf_loss_fwd_bwd")

@@ -85,10 +85,10 @@ int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_st
 /* ---- ray set-up ------------------------------------------------------------------------------
  * replaces: the ray preparation inside render(), RUN:129-158, with get_rays (HLP:288-297) and
  * ndc_rays (HLP:360-377).  Either `rays_o`/`rays_d` ([N,3] each) are given, or (c2w_host != NULL)
- * rays are generated for the full H x W image (N must equal H*W).  Output `rays` is the [N,11]
- * pack o3,d3,near,far,viewdir3 of RUN:152-158.                                                   */
+ * rays are generated for the N pixels pixel0 .. pixel0+N-1 (row-major) of the H x W image, so ranks can
+ * tile an image by rows.  Output `rays` is the [N,11] pack o3,d3,near,far,viewdir3 of RUN:152-158. */
 int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] row-major or NULL*/,
-                      const float* rays_o, const float* rays_d, int64_t N,
+                      const float* rays_o, const float* rays_d, int64_t N, int64_t pixel0,
                       int ndc, float near_, float far_, float* rays /*[N,11]*/, cfnerf_stream s);
 
 /* ---- fused forward ---------------------------------------------------------------------------
@@ -97,13 +97,15 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] r
  * MOD:358-416, FLW:189-268) and raw2outputs RUN:411-454, in one launch.
  *   rays    [N,11]          t_vals [S]            t_rand [N,S] or NULL (perturb == 0)
  *   eps     [K,4] = (eps_rgb0, eps_rgb1, eps_rgb2, eps_alpha) per latent sample (MOD:234,246 / 198,204)
- *   rgb_map [N,3,K]  disp_map [N,K]  depth_map [N,K]           (always written)
+ *   rgb_map [N,3,K]  disp_map [N,K]  depth_map [N,K]           (written unless all three are NULL and kstats is given)
  *   raw_opt [N,S,K,4], weights_opt [N,S,K], pts_opt [N,S,3]    (NULL = not wanted)
- *   entropy_out [1]  loss_entropy of MOD:286 (TRAIN only, may be NULL otherwise)                 */
+ *   kstats_opt [N,8]  fused reductions over the K latent samples, what the evaluation loop derives from the
+ *                     per-K maps at RUN:1122-1131: mean_K rgb (3) | np.std_K(rgb) * n/(n-1) (3) | mean_K disp | mean_K depth
+ *   entropy_out [1]   loss_entropy of MOD:286 (TRAIN only, may be NULL otherwise)                */
 int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand,
                       const float* eps, int64_t N, int S, int K, int flags,
                       float* rgb_map, float* disp_map, float* depth_map,
-                      float* raw_opt, float* weights_opt, float* pts_opt, float* entropy_out,
+                      float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out,
                       cfnerf_stream s);
 
 /* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]

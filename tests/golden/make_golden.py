@@ -311,6 +311,19 @@ def main():
                                 rgb_map=rgbs_e, disp_map=disp_e, depth_map=depth_e, rays_o=ro, rays_d=rd,
                                 ndc_o=no, ndc_d=nd)
 
+    # ---------------- G9: sparsification curves (HLP:382-438), the AUSE helper ----------------
+    var_vec = torch.tensor(rng.uniform(0.0, 1.0, 1000) ** 2, dtype=torch.float32)
+    err_vec = torch.tensor((rng.uniform(0.0, 1.0, 1000) * 0.5 + 0.5 * var_vec.numpy()) ** 2, dtype=torch.float32)
+    g9 = dict(var_vec=var_vec, err_vec=err_vec)
+    import contextlib, io
+    for ut in ("c", "v"):
+        for et in ("rmse", "mae"):
+            with contextlib.redirect_stdout(io.StringIO()):
+                a, b = HLP.sparsification_plot(var_vec, err_vec, uncert_type=ut, err_type=et)
+            g9[f"oracle_{ut}_{et}"] = a
+            g9[f"byvar_{ut}_{et}"] = b
+    out["g9_sparsification"] = g9
+
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **t2n(d))
