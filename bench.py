@@ -30,7 +30,7 @@ N_RAND, S, K, W, D = 1024, 128, 4, 256, 8
 
 def gemm_flops_per_point(W=256, ha=32, hr=64, ic=63, icv=27, F=4):
     """Algorithmic MACs per point (deduplicated flow heads) x 2."""
-    macs = ic * W + 3 * W * W + (W + ic) * W + 2 * W * W          # trunk (D = 8: layers 0, 1-4, 5 (skip), 6-7)
+    macs = ic * W + 4 * W * W + (W + ic) * W + 2 * W * W          # trunk (D = 8: layers 0, 1-4, 5 (skip), 6-7)
     macs += W * ha + W * W + (W + icv) * (W // 2) + (W // 2) * hr  # h_alpha, feature, views, h_rgb
     macs += hr * 18 * F + ha * 3 * F                               # live flow-parameter heads
     return 2 * macs

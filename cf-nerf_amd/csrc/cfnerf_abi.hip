@@ -172,6 +172,9 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         Stash& q = m->stash;
         a.st_enc = q.enc; a.st_gd = q.gd; a.st_h = q.h; a.st_feat = q.feat; a.st_v = q.v; a.st_ha = q.ha; a.st_hr = q.hr;
         a.st_theta = q.theta; a.st_z = q.z; a.st_at = q.at;
+        a.st_mbits = reinterpret_cast<uint32_t*>(q.mbits);
+        q.n_tiles = N * (int64_t)((S + kTileM - 1) / kTileM);
+        a.n_tiles = q.n_tiles;
         if (!a.raw) a.raw = q.raw;
         q.raw_used = a.raw;
         HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -24,7 +24,8 @@ struct BwdArgs {
     int32_t n_wg, nb;
     const float* g_theta;                                 // [P,128]   input (from the tail kernel)
     float *g_hr, *g_ha, *g_v, *g_feat, *g_h;              // outputs: pre-activation gradients, row-major per point
-    const float *st_v, *st_h;                             // stashed activations for the ReLU masks
+    const uint32_t* mbits;                                // [D+1][tiles][W/32][64] ReLU masks (fragment-ordered bit words)
+    int64_t n_tiles; int32_t S;                           // same tiling as the forward: tile = ray * chunks_per_ray + chunk
     float* dbp;                                           // [n_wg, nb] bias-gradient partials
     int32_t db_h, db_feat, db_v, db_ha, db_hr, db_theta;  // column offsets inside a dbp row
 };

@@ -253,33 +253,25 @@ __host__ __device__ inline size_t bwd_lds_bytes(int W, int ha) {
     return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4));
 }
 
-// Epilogue operands fetched BEFORE the MFMA block of a layer so their HBM/L2 latency hides under it:
-// the ReLU mask (stashed activation > 0) of this lane's output fragment and the running bias partial.
+// Epilogue operands fetched BEFORE the MFMA block of a layer so their latency hides under it: the ReLU mask of
+// this lane's output fragment (ONE bit word written by the forward in the same fragment layout) and the running
+// bias partial.
 template <int NTW>
 struct EpiPre {
-    float mv[NTW][2][16];
+    uint32_t mb[NTW];
     float db[NTW];
 };
 
 template <int NTW>
-__device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int nt0, int nts, const float* __restrict__ mask, int mld,
-                                             const float* __restrict__ dbp, int rows_valid) {
+__device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int nt0, int nts, const uint32_t* __restrict__ mbits,
+                                             const float* __restrict__ dbp) {
     const int lane = lane_id_opaque();
-    const int rbase = 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         int nt = nt0 + j * nts;
         if (nt >= nt_total) nt = nt0 < nt_total ? nt0 : 0;      // clamped: value unused
-        const int col = nt * 32 + (lane & 31);
-        e.db[j] = dbp[col];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const int rc = min(rr + rbase, rows_valid - 1);      // unconditional, clamped into the tile
-                e.mv[j][i][r] = (mask != nullptr) ? ld_stream(mask + (size_t)rc * mld + col) : 1.f;
-            }
+        e.db[j] = dbp[nt * 32 + (lane & 31)];
+        e.mb[j] = (mbits != nullptr) ? mbits[nt * 64 + lane] : 0xffffffffu;
     }
 }
 
@@ -297,6 +289,7 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
         const int col = nt * 32 + (lane & 31);
         float* lp = lds_dst + rbase * ld + col;
         float* gp = gdst + (size_t)rbase * gld + col;
+        const uint32_t mb = e.mb[j];
         float csum = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -304,7 +297,7 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const bool ok = rr + rbase < rows_valid;
-                const float v = (ok && e.mv[j][i][r] > 0.f) ? acc[i][j][r] : 0.f;
+                const float v = (ok && ((mb >> (i * 16 + r)) & 1u)) ? acc[i][j][r] : 0.f;
                 lp[rr * ld] = v;
                 if (ok) st_stream(gp + (size_t)rr * gld, v);
                 csum += v;
@@ -328,11 +321,16 @@ void bwd_data_kernel(const BwdArgs A) {
     const float* __restrict__ wp = A.wp;
     const int64_t P = A.P;
     float* dbp = A.dbp + (size_t)blockIdx.x * A.nb;           // this workgroup's bias-gradient partials
-    const int64_t n_tiles = (P + kTileM - 1) / kTileM;
+    const int64_t n_tiles = A.n_tiles;
+    const int cpr = (A.S + kTileM - 1) / kTileM;                // chunks per ray: the forward's tiling
+    constexpr int kMbStride = (W / 32) * 64;
+    const uint32_t* mb_all = A.mbits;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t p0 = tile * kTileM;
-        const int rows_valid = (int)min((int64_t)kTileM, P - p0);
+        const int64_t ray = tile / cpr;
+        const int chunk = (int)(tile - ray * cpr);
+        const int64_t p0 = ray * (int64_t)A.S + (int64_t)chunk * kTileM;
+        const int rows_valid = min(kTileM, A.S - chunk * kTileM);
         // ---- 0. g_theta tile -> act[:, 0:128)
         for (int idx = tid; idx < kTileM * (kThetaAll / 4); idx += kThreads) {
             const int row = idx >> 5, q = idx & 31;
@@ -353,10 +351,10 @@ void bwd_data_kernel(const BwdArgs A) {
             acc_zero(acc);
             const bool is_rgb = wave < 2;
             if (is_rgb) {
-                epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, 0, dbp + A.db_hr, rows_valid);
+                epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
                 mma_seg<1>(acc, T.bt_fr, wave, kWaves, wp, act, LD);
             } else {
-                epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, 0, dbp + A.db_ha, rows_valid);
+                epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
                 mma_seg<1>(acc, T.bt_fa, wave - 2, kWaves, wp, act + kThetaRgb, LD);
             }
             __syncthreads();
@@ -369,7 +367,7 @@ void bwd_data_kernel(const BwdArgs A) {
             f32x16 acc[2][NTV];
             EpiPre<NTV> e;
             acc_zero(acc);
-            epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, A.st_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
+            epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v);
             mma_seg<NTV>(acc, T.bt_hr, wave, kWaves, wp, act, LD);
             __syncthreads();
             store_bwd<NTV>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
@@ -380,7 +378,7 @@ void bwd_data_kernel(const BwdArgs A) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, 0, dbp + A.db_feat, rows_valid);
+            epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat);
             mma_seg<NTW>(acc, T.bt_vf, wave, kWaves, wp, act, LD);
             __syncthreads();
             store_bwd<NTW>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
@@ -391,7 +389,7 @@ void bwd_data_kernel(const BwdArgs A) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, NT, wave, kWaves, A.st_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W);
             mma_seg<NTW>(acc, T.bt_ft, wave, kWaves, wp, act, LD);
             mma_seg<NTW>(acc, T.bt_ha, wave, kWaves, wp, hs, HLD);
             __syncthreads();
@@ -403,7 +401,7 @@ void bwd_data_kernel(const BwdArgs A) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, NT, wave, kWaves, A.st_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
             mma_seg<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD);
             __syncthreads();
             store_bwd<NTW>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
@@ -675,8 +673,7 @@ static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int n_cu, 
         if (e != hipSuccess) return e;
         lds_set[wi] = lds;
     }
-    const int64_t tiles = (a.P + kTileM - 1) / kTileM;
-    int grid = (int)std::min<int64_t>(tiles, (int64_t)a.n_wg);
+    int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)a.n_wg);
     if (grid_out) *grid_out = grid;
     void* args[] = {const_cast<BwdArgs*>(&a)};
     return hipLaunchKernel(fn, dim3(grid), dim3(kThreads), args, lds, st);
@@ -907,7 +904,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     BwdArgs ba{};
     ba.tab = m->d_tab; ba.wp = m->d_packed; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
-    ba.st_v = q.v; ba.st_h = q.h; ba.dbp = B.d_dbp;
+    ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = B.d_dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
     if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));

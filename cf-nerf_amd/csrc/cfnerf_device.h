@@ -121,7 +121,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 template <int NTW, int ACT>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
-                                            float* __restrict__ gdst, int gld, int rows_valid) {
+                                            float* __restrict__ gdst, int gld, int rows_valid,
+                                            uint32_t* __restrict__ mbits = nullptr) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -132,6 +133,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
         const float bv = (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
         float* lp = lds_dst + rbase * ld + col0 + col;
         float* gp = (gdst != nullptr) ? gdst + (size_t)rbase * gld + col : nullptr;
+        uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -141,7 +143,11 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
                 if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                 lp[rr * ld] = v;
                 if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * gld, v);
+                bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
             }
+        // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
+        // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
+        if (mbits != nullptr) mbits[nt * 64 + lane] = bits;
     }
 }
 

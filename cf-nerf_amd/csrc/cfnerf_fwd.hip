@@ -103,6 +103,8 @@ void fused_fwd_kernel(const FwdArgs A) {
             // global point index of row 0 and number of valid rows of this tile
             const int64_t p0 = (MODE == 0) ? unit * (int64_t)S + (int64_t)chunk * kTileM : unit * (int64_t)kTileM;
             const int rows_valid = (MODE == 0) ? min(kTileM, S - chunk * kTileM) : (int)min((int64_t)kTileM, A.P - p0);
+            const int64_t tile_idx = (MODE == 0) ? unit * chunks_per_ray + chunk : unit;
+            constexpr int kMbStride = (W / 32) * 64;        // mask words per (layer, tile)
 
             // ---- 1. sampling along the ray (RUN:510-534): z for rows 0..64, pts for rows 0..63
             if (MODE == 0) {
@@ -157,7 +159,8 @@ void fused_fwd_kernel(const FwdArgs A) {
                 }
                 __syncthreads();
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
-                store_tiles<C::NTW, ACT_RELU>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid);
+                uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
+                store_tiles<C::NTW, ACT_RELU>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
                 __syncthreads();
             }
 
@@ -192,8 +195,9 @@ void fused_fwd_kernel(const FwdArgs A) {
                 __syncthreads();
                 mma_seg<C::NTV>(acc, T.vd, wave, kWaves, wp, act, LD);
                 __syncthreads();
+                uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
                 store_tiles<C::NTV, ACT_RELU>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
-                                              A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid);
+                                              A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)

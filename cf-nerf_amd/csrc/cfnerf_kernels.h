@@ -29,6 +29,8 @@ struct FwdArgs {
     // activation stash for the backward pass (all optional, row-major per point)
     float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
     float *st_at;                        // [P,K,2] alpha, transmittance T of the composite
+    uint32_t* st_mbits;                  // [D+1][tiles][W/32][64] ReLU masks as fragment-ordered bit words
+    int64_t n_tiles;                     // tiles of the launch (rays * chunks per ray)
 };
 
 hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int n_cu, hipStream_t st, int* grid_out);

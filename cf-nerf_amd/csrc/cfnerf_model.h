@@ -28,6 +28,8 @@ struct Stash {
     float *at = nullptr;     // [P,K,2] alpha, T
     float *dbp = nullptr;    // [n_wg, NB] per-workgroup bias-gradient partials
     float *gms = nullptr;    // [n_waves, 8] base-Gaussian gradient partials
+    float *mbits = nullptr;  // [D+1][tiles][W/32][64] u32 ReLU mask words (fragment order)
+    int64_t n_tiles = 0;
     // backward workspaces (same row-major-per-point convention)
     float *g_theta = nullptr;   // [P,128]  d loss / d theta (pre-tanh for the diagonal columns)
     float *g_hr = nullptr;      // [P,HR]
@@ -44,7 +46,7 @@ struct Stash {
     size_t partial_floats = 0;
 
     void release() {
-        float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays, &at, &dbp, &gms,
+        float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays, &at, &dbp, &gms, &mbits,
                          &g_theta, &g_hr, &g_ha, &g_v, &g_feat, &g_h, &partials};
         for (float** p : all) { if (*p) hipFree(*p); *p = nullptr; }
         cap_P = cap_N = 0; cap_K = 0; bytes = 0; valid = false; partial_floats = 0;
@@ -65,7 +67,7 @@ struct Stash {
         bool ok = al(&enc, (size_t)P * 64) && al(&gd, (size_t)P * 32) && al(&h, (size_t)D * P * W) && al(&feat, (size_t)P * W) &&
                   al(&v, (size_t)P * (W / 2)) && al(&ha, (size_t)P * c.h_alpha_size) && al(&hr, (size_t)P * c.h_rgb_size) &&
                   al(&theta, (size_t)P * kThetaAll) && al(&z, (size_t)P) && al(&raw, (size_t)P * k * 4) &&
-                  al(&rays, (size_t)n * 11) && al(&at, (size_t)P * k * 2) && al(&gms, (size_t)(n + 8) * 8) && al(&g_theta, (size_t)P * kThetaAll) && al(&g_hr, (size_t)P * c.h_rgb_size) &&
+                  al(&rays, (size_t)n * 11) && al(&at, (size_t)P * k * 2) && al(&gms, (size_t)(n + 8) * 8) && al(&mbits, (size_t)(D + 1) * (n * ((s + 63) / 64)) * (W / 32) * 64) && al(&g_theta, (size_t)P * kThetaAll) && al(&g_hr, (size_t)P * c.h_rgb_size) &&
                   al(&g_ha, (size_t)P * c.h_alpha_size) && al(&g_v, (size_t)P * (W / 2)) && al(&g_feat, (size_t)P * W) &&
                   al(&g_h, (size_t)D * P * W);
         if (!ok) { release(); return CFNERF_E_NOMEM; }
