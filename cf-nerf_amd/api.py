@@ -588,6 +588,22 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
 
 
 # --------------------------------------------------------------------------------------------
+def save_checkpoint(path, global_step, network_fn, optimizer=None, trainer=None):
+    """The reference's checkpoint dict (RUN:1085-1100): ``global_step``, ``network_fn_state_dict`` with the
+    DataParallel ``module.`` key prefix, ``optimizer_state_dict``.  Like the reference's loader (RUN:360, commented
+    out) create_nerf never restores the optimiser state; for a fused ``Trainer`` the flat Adam moments are saved."""
+    sd = network_fn.state_dict()
+    if not any(k.startswith("module.") for k in sd):
+        sd = OrderedDict(("module." + k, v) for k, v in sd.items())
+    if trainer is not None:
+        opt = {"exp_avg": trainer.exp_avg.detach().cpu(), "exp_avg_sq": trainer.exp_avg_sq.detach().cpu(), "t": trainer.t}
+    else:
+        opt = optimizer.state_dict() if optimizer is not None else {}
+    torch.save({'global_step': global_step, 'network_fn_state_dict': {k: v.detach().cpu() for k, v in sd.items()},
+                'optimizer_state_dict': opt}, path)
+    return path
+
+
 def create_nerf(args):
     """Instantiate the CF-NeRF model (RUN:317-409).  Returns
     ``(render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)``."""

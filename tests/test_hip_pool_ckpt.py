@@ -1,0 +1,74 @@
+"""-m gpu: device-side ray pool (RUN:860-884, 942-951; get_rays_np HLP:350-357) and checkpoint interop (RUN:345-378, 1085-1100)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import cfnerf_amd
+from oracle import cfnerf_oracle as O
+from util_hip import build_model, close, make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ray_pool_matches_get_rays_and_feeds_every_pixel_once_per_epoch():
+    rng = np.random.default_rng(0)
+    V, H, W, focal = 4, 6, 8, 9.5
+    images = torch.tensor(rng.uniform(0, 1, (V, H, W, 3)), dtype=torch.float32)
+    poses = torch.zeros(V, 3, 5)
+    for v in range(V):
+        a = 0.2 * v
+        poses[v, :, :3] = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        poses[v, :, 3] = torch.tensor(rng.uniform(-1, 1, 3))
+    i_train = [0, 2, 3]
+    pool = cfnerf_amd.RayPool(images, poses, H, W, focal, i_train, N_rand=16, shuffle=False)
+    assert len(pool) == 3 * H * W and pool.rays_rgb.shape == (3 * H * W, 3, 3)
+    for slot, v in enumerate(i_train):                      # the unshuffled pool is get_rays per view + the pixels
+        ro, rd = O.get_rays(H, W, focal, poses[v, :3, :4])
+        blk = pool.rays_rgb[slot * H * W:(slot + 1) * H * W].cpu()
+        close(blk[:, 0], ro.reshape(-1, 3), atol=0, rtol=0, what="origins")
+        close(blk[:, 1], rd.reshape(-1, 3), atol=1e-6, rtol=1e-6, what="directions")
+        assert torch.equal(blk[:, 2], images[v].reshape(-1, 3))
+    ref_rows = pool.rays_rgb.reshape(-1, 9).cpu()
+    pool._shuffle()
+    seen = []
+    for _ in range(len(pool) // 16):
+        batch_rays, target = pool.next_batch()
+        assert batch_rays.shape == (2, 16, 3) and target.shape == (16, 3)
+        seen.append(torch.cat([batch_rays[0], batch_rays[1], target], -1).cpu())
+    seen = torch.cat(seen)
+    assert pool.epoch == 1 and pool.i_batch == 0            # re-shuffled after the epoch (RUN:946-949)
+    key = lambda t: sorted(map(tuple, t.numpy().round(6).tolist()))
+    assert key(seen) == key(ref_rows)
+
+
+def test_checkpoint_roundtrip_in_the_reference_format():
+    cfg = O.OracleCfg(netwidth=64, K_samples=2)
+    _, kw_train, _, model, p, optimizer = build_model(cfg, 9)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "{:06d}_{:02d}.tar".format(1234, 1))              # RUN:1086
+        cfnerf_amd.save_checkpoint(path, 1234, model, optimizer)
+        ck = torch.load(path, map_location="cpu")
+        assert set(ck) == {"global_step", "network_fn_state_dict", "optimizer_state_dict"}
+        keys = set(ck["network_fn_state_dict"])
+        assert "module.pts_linears.5.weight" in keys and "module.flows_rgb.flow_3.diag_idx" in keys and "module.flows_alpha.triu_mask" in keys
+        assert not any(k.endswith("sample_alpha") for k in keys)                 # R9: eval latents are not in the state_dict
+        for k, v in p.items():
+            assert torch.equal(ck["network_fn_state_dict"]["module." + k], v)
+        # reload through create_nerf(ft_path=...) into a fresh model (RUN:345-374)
+        args = make_args(cfg, ft_path=path, no_reload=False)
+        kw2, _, start, _, _ = cfnerf_amd.create_nerf(args)
+        assert start == 1234
+        m2 = kw2["network_fn"].module
+        for k, v in p.items():
+            assert torch.equal(m2.view(k).cpu(), v), k
+        # a checkpoint with extra / missing keys is filtered like RUN:370
+        ck["network_fn_state_dict"]["module.not_a_key"] = torch.zeros(3)
+        del ck["network_fn_state_dict"]["module.rgb_mean"]
+        torch.save(ck, path)
+        kw3, _, _, _, _ = cfnerf_amd.create_nerf(make_args(cfg, ft_path=path, no_reload=False))
+        m3 = kw3["network_fn"].module
+        assert torch.equal(m3.view("pts_linears.0.weight").cpu(), p["pts_linears.0.weight"])
+        assert torch.equal(m3.view("rgb_mean").cpu(), torch.zeros(3))           # kept its init value
