@@ -21,10 +21,10 @@ namespace cfnerf {
 
 // ================================================================================================
 // 1. loss (RUN:1026-1050): one workgroup, deterministic.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, const float* __restrict__ entropy,
                  int64_t N, int K, float beta1, int64_t n_total, float* __restrict__ d_rgb, float* __restrict__ scalars) {
-    __shared__ double sh[2][256];
+    __shared__ double sh[2][1024];
     const float invK = 1.f / (float)K;
     const float bw = powf(0.8f / (float)K, -1.f / 7.f);                 // torch.pow(0.8/n, tensor(-1/7))  RUN:1036
     const float c2pi = powf(2.f * 3.14159265358979323846f, -1.5f);      // RUN:1039
@@ -56,7 +56,7 @@ void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target
     }
     sh[0][threadIdx.x] = nll; sh[1][threadIdx.x] = mse;
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
+    for (int d = 512; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) { sh[0][threadIdx.x] += sh[0][threadIdx.x + d]; sh[1][threadIdx.x] += sh[1][threadIdx.x + d]; }
         __syncthreads();
     }
@@ -598,19 +598,27 @@ __global__ void reduce_weights_kernel(const float* __restrict__ partials, int ns
     grad[i] = s;
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const BiasMap* __restrict__ maps, int n_maps,
                         float* __restrict__ grad) {
-    __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;                     // column of the bias partial table
-    float s = 0.f;
-    if (j < nb)
-        for (int w = part; w < n_wg; w += 4) s += dbp[(size_t)w * nb + j];      // coalesced across the 64 lanes
-    sh[part][lane] = s;
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;       // 16 row groups x 64 columns
+    const int j = blockIdx.x * 64 + lane;                             // column of the bias partial table
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < nb) {
+        int w = part;
+        for (; w + 48 < n_wg; w += 64) {                              // 4 independent loads in flight per lane
+            s0 += dbp[(size_t)w * nb + j]; s1 += dbp[(size_t)(w + 16) * nb + j];
+            s2 += dbp[(size_t)(w + 32) * nb + j]; s3 += dbp[(size_t)(w + 48) * nb + j];
+        }
+        for (; w < n_wg; w += 16) s0 += dbp[(size_t)w * nb + j];
+    }
+    sh[part][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && j < nb) {
-        const float tot = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += sh[q][lane];
         for (int q = 0; q < n_maps; ++q)
             if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) grad[maps[q].dst + (j - maps[q].col0)] = tot;
     }
@@ -777,7 +785,7 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
     if (N < 0 || K < 1 || n_total < N) return bfail(CFNERF_E_INVALID, "bad N/K/n_total");
     if (N == 0) return CFNERF_OK;
     if (!rgb_map || !target || !d_rgb_map || !scalars_out) return bfail(CFNERF_E_INVALID, "NULL argument");
-    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, rgb_map, target, entropy, N, K, beta1, n_total,
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, rgb_map, target, entropy, N, K, beta1, n_total,
                        d_rgb_map, scalars_out);
     BHIP(hipGetLastError());
     return CFNERF_OK;
@@ -926,7 +934,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, kMaxSplit,
                        n_params, grad_flat);
     BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(256), 0, st, B.d_dbp, grid_bd, B.nb,
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, B.d_dbp, grid_bd, B.nb,
                        B.d_bias_maps, (int)B.bias_maps.size(), grad_flat);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N, m->flat, d_entropy, grad_flat);
