@@ -177,9 +177,18 @@ def main():
     if rank == 0:
         rays_per_s = N_RAND * world * args.steps / dt
         fl = gemm_flops_per_point(W) * N_RAND * S          # forward GEMM FLOPs of one launch of the fused forward kernel
-        roof = {"bound": "mfma", "kernel": "fused_fwd_kernel<256,rays>", "achieved": fl / (fwd_ms * 1e-3) / 1e12,
-                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": None,
-                "launch_ms": fwd_ms, "flops_per_launch": fl}
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
+        traffic, mfma_busy = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)[mode]
+            traffic, mfma_busy = tj["hbm_bytes_per_launch"], tj.get("mfma_busy_frac")
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": f"fused_fwd_kernel<256,rays,{'train' if mode == 'train' else 'eval'}>",
+                "achieved": fl / (fwd_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": traffic,
+                "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.txt)",
+                "mfma_busy_frac_pmc": mfma_busy, "launch_ms": fwd_ms, "flops_per_launch": fl}
         roof["frac"] = roof["achieved"] / roof["peak"]
         out = {
             "metric": "rays/sec (train step)" if mode == "train" else "rays/sec (eval render, fused forward)",
