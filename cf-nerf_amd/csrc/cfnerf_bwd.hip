@@ -444,7 +444,7 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 //      through double-buffered LDS (32 points per stage) with register prefetch, so every dY / X element is
 //      read from HBM exactly once and the loads of stage s+1 fly under the 128 MFMAs per wave of stage s.
 constexpr int kDwRows = 32;                   // points per LDS stage
-constexpr int kDwSmallGroup = 5;              // dw_small_kernel: point-pairs per register group (2 groups in flight)
+constexpr int kDwSmallGroup = 4;              // dw_small_kernel: point-pairs per register group (2 groups in flight)
 constexpr int kDwThreads = 512;
 __global__ __launch_bounds__(kDwThreads, 2)
 void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
@@ -526,18 +526,24 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
 }
 
-// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads): ONE WAVE per block computes a
-//      128 (n) x 64 (k) tile of one split, operands straight from global memory with a deep register pipeline.
-//      Wave-granular blocks: only k-slices that exist are launched and ~8 of them fit per CU.
-__global__ __launch_bounds__(64, 2)
+// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads): a block computes ONE 128 (n) x 64 (k)
+//      tile of one split; its 4 waves take a quarter of the block's points each (operands straight from global
+//      memory with a deep register pipeline) and tree-reduce their accumulators through LDS.  Only k-slices that
+//      exist are launched; the 4x intra-block split puts ~2 waves on every SIMD to hide the HBM latency.
+constexpr int kDwSmallWaves = 4;
+__global__ __launch_bounds__(64 * kDwSmallWaves, 2)
 void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
                      const float* __restrict__ zeros) {
-    const int lane = lane_id_opaque();
+    __shared__ float red[2][8][16][64];                    // two accumulator sets of 128 regs x 64 lanes (64 KB)
+    const int lane = lane_id_opaque(), wave = wave_id();
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
     const int kw0 = t.k0 + 64 * blk.kslice;
-    if (kw0 >= t.K) return;
-    const int64_t pb = blk.pb, pe = blk.pe;
+    // this wave's quarter of the block's point range (multiples of the pipeline step)
+    const int64_t span = blk.pe - blk.pb;
+    int64_t q4 = (span + kDwSmallWaves - 1) / kDwSmallWaves;
+    q4 = (q4 + 4 * kDwSmallGroup - 1) / (4 * kDwSmallGroup) * (4 * kDwSmallGroup);
+    const int64_t pb = min(blk.pe, blk.pb + wave * q4), pe = min(blk.pe, pb + q4);
     const int i = lane & 31, kk = lane >> 5;
     const int ncol = t.n0 + 4 * i, kcol = kw0 + 2 * i;
     const bool n_ok = ncol + 4 <= t.Npad;          // the 16-B vector stays inside the readable part of the dY row
@@ -585,7 +591,33 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
             for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(ha[q][tn], hb[q][0], acc[tn][0]); acc[tn][1] = CFN_MFMA(ha[q][tn], hb[q][1], acc[tn][1]); }
         __builtin_amdgcn_sched_barrier(0);
     }
-    dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0, kw0, lane);
+    // tree reduction of the 4 waves' accumulators through LDS: (2,3) -> (0,1), then 1 -> 0
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[slot][a * 2 + b][r][lane] = acc[a][b][r];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += red[slot][a * 2 + b][r][lane];
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) {
+        add(0);
+        dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0, kw0, lane);
+    }
 }
 
 // ================================================================================================
@@ -927,7 +959,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         BHIP(hipGetLastError());
     }
     if (B.n_blocks_small > 0) {
-        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(64), 0, st, B.d_tiles_small, B.d_blocks_small,
+        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(64 * kDwSmallWaves), 0, st, B.d_tiles_small, B.d_blocks_small,
                            B.d_partials, n_params, B.d_zeros);
         BHIP(hipGetLastError());
     }
