@@ -406,7 +406,7 @@ class _RenderFn(torch.autograd.Function):
         raw = torch.empty(N, S, K, 4, device=dev)
         pts = torch.empty(N, S, 3, device=dev) if want_pts else None
         ent = torch.zeros(1, device=dev)
-        L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K,
+        L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), None, L.ptr(eps), N, S, K,
                                           flags | L.F_STASH, L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), None,
                                           L.ptr(pts), None, L.ptr(ent), L.stream()), "cfnerf_render_fwd")
         ctx.model = model
@@ -433,7 +433,7 @@ class _RenderFn(torch.autograd.Function):
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, uniformsample, retraw=False,
                 lindisp=False, K_samples=0, perturb=0., N_importance=0, network_fine=None, white_bkgd=False,
                 raw_noise_std=0., verbose=False, pytest=False, t_rand=None, eps_alpha=None, eps_rgb=None,
-                t_vals=None, retweights=False):
+                t_vals=None, retweights=False, hierarchical_extension=False, u_fine=None):
     """Volumetric rendering of a ray batch (RUN:457-553) in ONE fused launch.
 
     Returns ``{'rgb_map' [N,3,K], 'disp_map' [N,K], 'depth_map' [N,K]}`` plus ``raw``, ``loss_entropy``
@@ -442,8 +442,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
     reference silently ignores (there is no fine pass) - are rejected.
     """
     _need_gpu(ray_batch, "ray_batch")
+    if hierarchical_extension and N_importance and N_importance > 0:
+        return _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is_train, lindisp, perturb, white_bkgd,
+                                         t_rand, eps_alpha, eps_rgb, t_vals, u_fine)
     if N_importance and N_importance > 0 or network_fine is not None:
-        raise NotImplementedError("the reference has no hierarchical/fine pass (N_importance is dead there); refusing to ignore it")
+        raise NotImplementedError("the reference has no hierarchical/fine pass (N_importance is dead there); refusing to ignore it "
+                                  "(pass hierarchical_extension=True for the coarse+fine EXTENSION of this build)")
     if ray_batch.shape[-1] != 11:
         raise ValueError("ray_batch must be [N,11] = o3,d3,near,far,viewdir3 (use_viewdirs=True)")
     model = _unwrap(network_fn)
@@ -488,7 +492,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
     pts = torch.empty(N, S, 3, device=dev) if is_train else None
     wts = torch.empty(N, S, K, device=dev) if retweights else None
     ent = torch.zeros(1, device=dev)
-    L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(eps), N, S, K, flags,
+    L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), None, L.ptr(eps), N, S, K, flags,
                                       L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), L.ptr(wts), L.ptr(pts), None, L.ptr(ent),
                                       L.stream()), "cfnerf_render_fwd")
     ret = {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth}
@@ -498,6 +502,60 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
         ret['pts'] = pts
     if retweights:
         ret['weights'] = wts
+    return ret
+
+
+def _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is_train, lindisp, perturb, white_bkgd, t_rand,
+                              eps_alpha, eps_rgb, t_vals, u_fine):
+    """EXTENSION, not in the reference: classic coarse+fine sampling through the single CF-NeRF network.
+    Coarse pass on ``t_vals`` (default ``linspace(0,1,N_samples)``), ``cfnerf_sample_pdf`` on the K-mean coarse weights,
+    fine pass on the merged depths.  Forward only (no autograd).  Parity is pinned against the build's own CPU
+    restatement of nerf-pytorch's ``sample_pdf`` only - the reference has nothing to compare with."""
+    model = _unwrap(network_fn)
+    if torch.is_grad_enabled() and model.flat.requires_grad and is_train:
+        raise NotImplementedError("the hierarchical extension is forward-only; wrap the call in torch.no_grad()")
+    dev = ray_batch.device
+    rays = _f32c(ray_batch)
+    N, K = rays.shape[0], model.K_samples
+    tv = torch.linspace(0., 1., steps=N_samples).to(dev) if t_vals is None else t_vals.to(dev, torch.float32).contiguous()
+    S = tv.shape[0]
+    tr = None
+    if perturb > 0.:
+        tr = _f32c((torch.rand([N, S]) if t_rand is None else t_rand).to(dev))
+    if eps_alpha is not None or eps_rgb is not None:
+        eps = torch.cat([eps_rgb, eps_alpha], -1).to(dev, torch.float32).contiguous()
+    else:
+        eps = model.draw_eps() if is_train else model.eval_eps()
+    if u_fine is None:      # det=(perturb == 0.) in nerf-pytorch
+        u_fine = torch.linspace(0., 1., steps=N_importance).expand(N, N_importance) if not perturb > 0. else torch.rand(N, N_importance)
+    u = _f32c(u_fine.to(dev))
+    flags = (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0) | (L.F_TRAIN if is_train else 0)
+    model._sync()
+    lib = L.lib()
+
+    def launch(S_, z_in, want_w):
+        rgb, disp, depth = torch.empty(N, 3, K, device=dev), torch.empty(N, K, device=dev), torch.empty(N, K, device=dev)
+        wts = torch.empty(N, S_, K, device=dev) if want_w else None
+        ent = torch.zeros(1, device=dev)
+        L.check(lib.cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(tv), L.ptr(tr) if z_in is None else None, L.ptr(z_in), L.ptr(eps),
+                                      N, S_, K, flags, L.ptr(rgb), L.ptr(disp), L.ptr(depth), None, L.ptr(wts), None, None, L.ptr(ent),
+                                      L.stream()), "cfnerf_render_fwd")
+        return rgb, disp, depth, wts, ent
+    rgb0, disp0, depth0, w0, _ = launch(S, None, True)
+    # the coarse depths are needed by the resampler: recompute them with the same formula on the device tensors
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    z = near * (1. - tv) + far * tv if not lindisp else 1. / (1. / near * (1. - tv) + 1. / far * tv)
+    z = z.expand(N, S)
+    if tr is not None:
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        z = torch.cat([z[..., :1], mids], -1) + (torch.cat([mids, z[..., -1:]], -1) - torch.cat([z[..., :1], mids], -1)) * tr
+    z = z.contiguous()
+    z_all = torch.empty(N, S + N_importance, device=dev)
+    L.check(lib.cfnerf_sample_pdf(L.ptr(z), L.ptr(w0), L.ptr(u), N, S, K, N_importance, L.ptr(z_all), L.stream()), "cfnerf_sample_pdf")
+    rgb, disp, depth, _, ent = launch(S + N_importance, z_all, False)
+    ret = {'rgb_map': rgb, 'disp_map': disp, 'depth_map': depth, 'rgb0': rgb0, 'disp0': disp0, 'depth0': depth0, 'z_vals': z_all}
+    if is_train:
+        ret['loss_entropy'] = ent.reshape(1, 1, 1).expand(N * (S + N_importance), K, 1)
     return ret
 
 

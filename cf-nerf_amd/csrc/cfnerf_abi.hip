@@ -144,13 +144,13 @@ static int check_common(cfnerf_model* m, int K) {
     return CFNERF_OK;
 }
 
-int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand, const float* eps,
-                      int64_t N, int S, int K, int flags, float* rgb_map, float* disp_map, float* depth_map,
+int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand, const float* z_vals_opt,
+                      const float* eps, int64_t N, int S, int K, int flags, float* rgb_map, float* disp_map, float* depth_map,
                       float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out, cfnerf_stream s) {
     if (int rc = check_common(m, K)) return rc;
     if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
     if (N == 0) return CFNERF_OK;            // empty batch: nothing to do (buffers may be NULL)
-    if (!rays || !t_vals || !eps) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (!rays || !eps || (!t_vals && !z_vals_opt)) return fail(CFNERF_E_INVALID, "NULL argument");
     const bool maps = rgb_map && disp_map && depth_map;
     if (!maps && (rgb_map || disp_map || depth_map)) return fail(CFNERF_E_INVALID, "rgb_map/disp_map/depth_map must be given together");
     if (!maps && !kstats_opt) return fail(CFNERF_E_INVALID, "either the per-K maps or kstats_opt must be requested");
@@ -161,7 +161,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     FwdArgs a{};
     a.tab = m->d_tab; a.wp = m->d_packed; a.flat = m->flat;
-    a.rays = rays; a.t_vals = t_vals; a.t_rand = t_rand; a.eps = eps;
+    a.rays = rays; a.t_vals = t_vals; a.t_rand = z_vals_opt ? nullptr : t_rand; a.z_in = z_vals_opt; a.eps = eps;
     a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
     a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt; a.kstats = kstats_opt;
@@ -187,6 +187,16 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, st));
+    return CFNERF_OK;
+}
+
+int cfnerf_sample_pdf(const float* z_vals, const float* weights, const float* u, int64_t N, int S, int K, int N_importance,
+                      float* z_out, cfnerf_stream s) {
+    if (N < 0 || S < 3 || K < 1 || N_importance < 1) return fail(CFNERF_E_INVALID, "bad N/S/K/N_importance (S >= 3)");
+    if (S + N_importance > 1024) return fail(CFNERF_E_UNSUPPORTED, "S + N_importance must be <= 1024");
+    if (N == 0) return CFNERF_OK;
+    if (!z_vals || !weights || !u || !z_out) return fail(CFNERF_E_INVALID, "NULL argument");
+    HIPCHK(launch_sample_pdf(z_vals, weights, u, N, S, K, N_importance, z_out, (hipStream_t)s));
     return CFNERF_OK;
 }
 

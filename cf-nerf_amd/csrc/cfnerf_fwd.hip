@@ -112,13 +112,17 @@ void fused_fwd_kernel(const FwdArgs A) {
                     const int s = chunk * kTileM + tid;
                     float zv = 0.f, px = 0.f, py = 0.f, pz = 0.f;
                     if (s < S) {
-                        const bool lind = (A.flags & CFNERF_F_LINDISP) != 0;
-                        const float zc = zlin_f(A.t_vals[s], nearv, farv, lind);
-                        zv = zc;
-                        if (A.t_rand != nullptr) {                                                 // RUN:518-532
-                            const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(A.t_vals[s + 1], nearv, farv, lind) + zc);
-                            const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(A.t_vals[s - 1], nearv, farv, lind));
-                            zv = lower + (upper - lower) * A.t_rand[unit * (int64_t)S + s];
+                        if (A.z_in != nullptr) {
+                            zv = A.z_in[unit * (int64_t)S + s];                                    // explicit depths (extension)
+                        } else {
+                            const bool lind = (A.flags & CFNERF_F_LINDISP) != 0;
+                            const float zc = zlin_f(A.t_vals[s], nearv, farv, lind);
+                            zv = zc;
+                            if (A.t_rand != nullptr) {                                             // RUN:518-532
+                                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(A.t_vals[s + 1], nearv, farv, lind) + zc);
+                                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(A.t_vals[s - 1], nearv, farv, lind));
+                                zv = lower + (upper - lower) * A.t_rand[unit * (int64_t)S + s];
+                            }
                         }
                         px = ro[0] + rd[0] * zv; py = ro[1] + rd[1] * zv; pz = ro[2] + rd[2] * zv;  // RUN:534
                         if (tid < kTileM) {
@@ -475,6 +479,72 @@ __global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int u
     float* r = out + n * 11;
     r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
     r[6] = nearv; r[7] = farv; r[8] = vd[0]; r[9] = vd[1]; r[10] = vd[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// EXTENSION: hierarchical resampling (semantics of nerf-pytorch's sample_pdf, the reference's upstream; the
+// reference itself has no second pass).  One wave per ray.
+constexpr int kPdfMax = 1024;            // S + N_importance
+__global__ __launch_bounds__(64)
+void sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ weights, const float* __restrict__ u,
+                       int64_t N, int S, int K, int Ni, float* __restrict__ z_out) {
+    __shared__ float cdf[kPdfMax], bins[kPdfMax], zall[kPdfMax];
+    const int lane = lane_id();
+    const int64_t n = blockIdx.x;
+    if (n >= N) return;
+    const float* zr = z_vals + n * (int64_t)S;
+    const int nb = S - 1;                 // bins = mids of consecutive depths; cdf has nb entries (first = 0)
+    const int nw = S - 2;                 // weights[..., 1:-1]
+    for (int j = lane; j < nb; j += 64) bins[j] = 0.5f * (zr[j + 1] + zr[j]);
+    // K-mean of the inner weights (+1e-5, "prevent nans"), their total
+    float part = 0.f;
+    for (int j = lane; j < nw; j += 64) {
+        float w = 0.f;
+        for (int k = 0; k < K; ++k) w += weights[(n * S + (j + 1)) * (int64_t)K + k];
+        w = w / (float)K + 1e-5f;
+        zall[j] = w;                      // scratch
+        part += w;
+    }
+    const float total = wave_sum(part);
+    __syncthreads();
+    // cdf = cat([0, cumsum(pdf)])
+    float carry = 0.f;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int base = 0; base < nw; base += 64) {
+        const int j = base + lane;
+        float v = (j < nw) ? zall[j] / total : 0.f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+        if (j < nw) cdf[j + 1] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+    __syncthreads();
+    for (int j = lane; j < S; j += 64) zall[j] = zr[j];
+    for (int i = lane; i < Ni; i += 64) {
+        const float ui = u[n * (int64_t)Ni + i];
+        int lo = 0, hi = nb;              // searchsorted(cdf, u, right=True): first index with cdf > u
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= ui) lo = mid + 1; else hi = mid; }
+        const int below = max(0, lo - 1), above = min(nb - 1, lo);
+        const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (ui - c0) / denom;
+        zall[S + i] = b0 + t * (b1 - b0);
+    }
+    __syncthreads();
+    // merge + sort (rank sort, stable): z_vals = sort(cat([z_vals, z_samples]))
+    const int M = S + Ni;
+    for (int a = lane; a < M; a += 64) {
+        const float va = zall[a];
+        int rank = 0;
+        for (int b = 0; b < M; ++b) { const float vb = zall[b]; rank += (vb < va || (vb == va && b < a)) ? 1 : 0; }
+        z_out[n * (int64_t)M + rank] = va;
+    }
+}
+
+hipError_t launch_sample_pdf(const float* z, const float* w, const float* u, int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st) {
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(64), 0, st, z, w, u, N, S, K, Ni, z_out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

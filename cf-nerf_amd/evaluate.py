@@ -69,7 +69,7 @@ def render_uncertainty(H, W, focal, c2w, network_fn, near=0., far=1., ndc=True, 
     rgb = disp = depth = None
     if want_maps:
         rgb, disp, depth = torch.empty(n, 3, K, device=dev), torch.empty(n, K, device=dev), torch.empty(n, K, device=dev)
-    L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(packed), L.ptr(t_vals), None, L.ptr(eps), n, S, K, flags, L.ptr(rgb), L.ptr(disp),
+    L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(packed), L.ptr(t_vals), None, None, L.ptr(eps), n, S, K, flags, L.ptr(rgb), L.ptr(disp),
                                   L.ptr(depth), None, None, None, L.ptr(kst), None, L.stream()), "cfnerf_render_fwd")
     h = r1 - r0
     out = dict(rgb_mean=kst[:, 0:3].reshape(h, W, 3), rgb_unc=kst[:, 3:6].reshape(h, W, 3), disp_mean=kst[:, 6].reshape(h, W),

@@ -103,7 +103,7 @@ class Trainer:
         net._sync()
         flags = L.F_STASH | L.F_TRAIN | (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0)
         L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(_f32c(t_rand) if t_rand is not None else None),
-                                      L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
+                                      None, L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
                                       None, None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
         L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
                                         C.c_float(self.beta1), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),

@@ -96,6 +96,8 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] r
  * positional encoding HLP:21-69, NeRF_Flows.forward MOD:188-291 (TriangularSylvesterNeRF
  * MOD:358-416, FLW:189-268) and raw2outputs RUN:411-454, in one launch.
  *   rays    [N,11]          t_vals [S]            t_rand [N,S] or NULL (perturb == 0)
+ *   z_vals_opt [N,S] or NULL: explicit sample depths per ray (then t_vals / t_rand are not read) - used by the
+ *                     hierarchical-sampling EXTENSION below, which the reference does not have
  *   eps     [K,4] = (eps_rgb0, eps_rgb1, eps_rgb2, eps_alpha) per latent sample (MOD:234,246 / 198,204)
  *   rgb_map [N,3,K]  disp_map [N,K]  depth_map [N,K]           (written unless all three are NULL and kstats is given)
  *   raw_opt [N,S,K,4], weights_opt [N,S,K], pts_opt [N,S,3]    (NULL = not wanted)
@@ -103,10 +105,17 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] r
  *                     per-K maps at RUN:1122-1131: mean_K rgb (3) | np.std_K(rgb) * n/(n-1) (3) | mean_K disp | mean_K depth
  *   entropy_out [1]   loss_entropy of MOD:286 (TRAIN only, may be NULL otherwise)                */
 int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand,
-                      const float* eps, int64_t N, int S, int K, int flags,
+                      const float* z_vals_opt, const float* eps, int64_t N, int S, int K, int flags,
                       float* rgb_map, float* disp_map, float* depth_map,
                       float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out,
                       cfnerf_stream s);
+
+/* EXTENSION (not in the reference, whose N_importance / network_fine are dead parameters, RUN:467-468; the
+ * semantics restated are those of the reference's upstream, yenchenlin/nerf-pytorch sample_pdf): inverse-CDF
+ * resampling of N_importance depths per ray from the K-mean of the coarse weights, merged and sorted with the
+ * coarse depths.  z_vals [N,S], weights [N,S,K], u [N,N_importance] in [0,1] -> z_out [N,S+N_importance].      */
+int cfnerf_sample_pdf(const float* z_vals, const float* weights, const float* u, int64_t N, int S, int K,
+                      int N_importance, float* z_out, cfnerf_stream s);
 
 /* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]
  * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].                   */

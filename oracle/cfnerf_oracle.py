@@ -6,10 +6,14 @@ This file is a functional PyTorch-CPU restatement of the reference algorithm
 may import it.  Nothing under ``cf-nerf_amd/`` imports it, and the product path
 never falls back to it.
 
-Parity status: PINNED.  Every function below is checked in
-``tests/test_oracle_golden.py`` against golden vectors produced by importing
-the real reference in the build container (``tests/golden/make_golden.py``,
-fixtures ``tests/golden/*.npz``).
+Parity status: PINNED for the reference's path - every function down to
+``train_step`` is checked in ``tests/test_oracle_golden.py`` against golden
+vectors produced by importing the real reference in the build container
+(``tests/golden/make_golden.py``, fixtures ``tests/golden/*.npz``).
+PARITY UNPINNED for the EXTENSION section at the end of the file
+(``sample_pdf`` / ``render_rays_hierarchical``): the reference has no
+hierarchical pass, so those two functions restate its upstream's published
+algorithm and have no golden vector.
 
 Abbreviations in the citations (all paths relative to the reference root):
   RUN = run_nerf_uncertainty_NF.py   HLP = run_nerf_helpers.py
@@ -476,3 +480,48 @@ def train_step(p: Dict[str, Tensor], packed_rays: Tensor, target_s: Tensor, cfg:
     scal = {k: float(v.detach()) for k, v in L.items()}
     scal["loss_entropy"] = float(ret["loss_entropy"].detach())
     return scal, grads, {k: v.detach() for k, v in ret.items() if v is not None}
+
+
+# --------------------------------------------------------------------------
+# EXTENSION oracle - PARITY UNPINNED by poetrywanderer/CF-NeRF: the reference has no hierarchical pass
+# (N_importance / network_fine are dead parameters, RUN:467-468; `searchsorted` survives only in a comment,
+# HLP:9-11).  What is restated here is the published algorithm of its upstream, yenchenlin/nerf-pytorch
+# (run_nerf_helpers.py `sample_pdf`, run_nerf.py render_rays lines "if N_importance > 0"), adapted to K latent
+# samples by driving the resampling with the K-mean of the coarse weights.  No golden vector exists for it.
+# --------------------------------------------------------------------------
+def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor) -> Tensor:
+    """bins [N,M], weights [N,M-1], u [N,Ni] in [0,1] -> samples [N,Ni] (inverse-CDF sampling)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    inds_g = torch.stack([below, above], -1)
+    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+def render_rays_hierarchical(p, ray_batch: Tensor, cfg: OracleCfg, eps_alpha, eps_rgb, is_train: bool, t_vals_coarse: Tensor,
+                             u: Tensor, t_rand: Optional[Tensor] = None, lindisp=False, white_bkgd=False):
+    """Coarse pass on t_vals_coarse, resample u.shape[1] depths from the K-mean coarse weights, fine pass on the
+    merged sorted depths through the SAME network (network_fine is None in the reference)."""
+    coarse = render_rays(p, ray_batch, cfg, eps_alpha, eps_rgb, is_train, t_rand, lindisp, white_bkgd, t_vals=t_vals_coarse)
+    z = coarse["z_vals"]
+    z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
+    w = coarse["weights"].mean(-1)                                   # [N,S]
+    z_samples = sample_pdf(z_mid, w[..., 1:-1], u).detach()
+    z_all, _ = torch.sort(torch.cat([z, z_samples], -1), -1)
+    rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
+    raw, ent = run_network(p, pts, viewdirs, eps_alpha, eps_rgb, cfg, is_test=not is_train)
+    rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_all, rays_d, white_bkgd)
+    return dict(rgb_map=rgb_map, disp_map=disp_map, depth_map=depth_map, weights=weights, z_vals=z_all, z_samples=z_samples,
+                rgb0=coarse["rgb_map"], disp0=coarse["disp_map"], depth0=coarse["depth_map"], loss_entropy=ent)

@@ -245,3 +245,34 @@ def test_empty_batch_and_bad_arguments():
         cfnerf_amd.render_rays(torch.zeros(4, 11, device=DEV), **dict(kw, N_importance=64))
     with pytest.raises(ValueError):
         model.module(torch.zeros(3, 63, device=DEV), False, True)
+
+
+# ---------------------------------------------------------------- EXTENSION: coarse + fine sampling (not in the reference)
+@pytest.mark.parametrize("perturb", [0., 1.])
+def test_hierarchical_extension_vs_own_restatement(perturb):
+    """Parity here is UNPINNED by the reference (it has no second pass): the oracle restates
+    nerf-pytorch's sample_pdf; this only shows the HIP resampler + explicit-depth launch agree with it."""
+    cfg = O.OracleCfg(netwidth=128, K_samples=3)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, 123)
+    rng = np.random.default_rng(8)
+    N, S, Ni = 21, 64, 128
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    tvc = torch.linspace(0., 1., steps=S)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32) if perturb else None
+    u = torch.tensor(rng.uniform(0, 1, (N, Ni)), dtype=torch.float32) if perturb else torch.linspace(0., 1., steps=Ni).expand(N, Ni).contiguous()
+    ea = torch.tensor(rng.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((3, 3)), dtype=torch.float32)
+    kw = {k: v for k, v in kw_test.items() if k not in ("use_viewdirs", "N_samples", "N_importance", "perturb")}
+    with torch.no_grad():
+        ret = cfnerf_amd.render_rays(packed.to(DEV), N_samples=S, N_importance=Ni, perturb=perturb, hierarchical_extension=True,
+                                     t_rand=t_rand, u_fine=u, eps_alpha=ea, eps_rgb=er, **kw)
+    r = O.render_rays_hierarchical(p, packed, cfg, ea, er, False, tvc, u, t_rand=t_rand)
+    assert ret["z_vals"].shape == (N, S + Ni)
+    assert bool((ret["z_vals"][:, 1:] >= ret["z_vals"][:, :-1]).all())
+    close(ret["rgb0"], r["rgb0"], what="coarse rgb")
+    close(ret["z_vals"], r["z_vals"], atol=2e-5, rtol=1e-4, what="merged depths")
+    close(ret["rgb_map"], r["rgb_map"], atol=1e-4, rtol=1e-3, what="fine rgb")          # looser: depths move by ~1e-5
+    close(ret["depth_map"], r["depth_map"], atol=1e-4, rtol=1e-3, what="fine depth")
+    with pytest.raises(NotImplementedError):                                            # default stays reference-faithful
+        cfnerf_amd.render_rays(packed.to(DEV), N_samples=S, N_importance=Ni, perturb=0., **kw)
