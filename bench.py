@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["train", "eval"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement reported next to the fp32 line")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32 = exact-fp32 MFMA (default, the measured parity path); bf16x3 = opt-in split-bf16 MFMA mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +138,7 @@ def main():
     rays, target, (H, Wd, focal) = synth_batch(rank, N_RAND, dev)
     lib = L.lib()
     lib.cfnerf_timing_enable(net.handle, 1)
+    net.set_precision(args.precision)
     g = torch.Generator(device=dev).manual_seed(1234)           # same latent samples on every rank
 
     if mode == "train":
@@ -174,6 +178,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the opt-in split-bf16 mode, measured the same way right after (every rank runs it: the all-reduce is inside)
+    alt = None
+    if args.precision == "fp32" and not args.no_alt:
+        net.set_precision("bf16x3")
+        for _ in range(min(3, args.warmup) or 1):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dta = time.perf_counter() - t1
+        alt_fwd_ms = lib.cfnerf_timing_last_ms(net.handle, 0)
+        if world > 1 or force_dist:
+            t = torch.tensor([dta], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dta = float(t.item())
+        net.set_precision("fp32")
+        alt = {"precision": "bf16x3 (opt-in): fp32 operands carried as hi+lo bf16, product = hi*hi + hi*lo + lo*hi on "
+                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward + backward-data (weight-gradient GEMMs stay fp32); "
+                            "held to the same parity tolerances (tests/test_hip_bf16x3.py)",
+               "value": N_RAND * world * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
+               "fwd_launch_ms": alt_fwd_ms}
+
     if rank == 0:
         rays_per_s = N_RAND * world * args.steps / dt
         fl = gemm_flops_per_point(W) * N_RAND * S          # forward GEMM FLOPs of one launch of the fused forward kernel
@@ -194,14 +222,17 @@ def main():
             "metric": "rays/sec (train step)" if mode == "train" else "rays/sec (eval render, fused forward)",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3-split MFMA, f32 accumulate (opt-in mode)", "data": "synthetic",
             "config": {"workload": f"LLFF-fern-shaped synthetic rays, N_rand={N_RAND}/GPU, S={S} (reference table, single pass), "
-                                   f"K={K}, W={W}, D={D}, NDC, mode={mode}",
+                                   f"K={K}, W={W}, D={D}, NDC, mode={mode}, precision={args.precision}",
                        "parallelism": f"ray-sharded dp{world}" + (", 1 RCCL all-reduce of flat grads/step" if mode == "train" and world > 1 else "")},
             "roofline": roof,
         }
         if extra_ms:
             out["kernel_ms"] = dict(fwd=fwd_ms, **extra_ms)
+        if alt is not None:
+            alt["fwd_fp32_equiv_tflops"] = fl / (alt["fwd_launch_ms"] * 1e-3) / 1e12
+            out["alt_precision"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode)
         print(json.dumps(out), flush=True)

@@ -281,6 +281,12 @@ class NeRF_Flows(nn.Module):
     def handle(self):
         return self._h
 
+    def set_precision(self, mode: str):
+        """'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (opt-in split-bf16 MFMA in the forward's dense layers)."""
+        code = {"fp32": 0, "bf16x3": 1}[mode]
+        L.check(L.lib().cfnerf_model_set_precision(self._h, code), "cfnerf_model_set_precision")
+        self.precision = mode
+
     def eval_eps(self):
         """[K,4] eval latents: the fixed buffers with the LAST sample zeroed (MOD:199,205)."""
         e = torch.cat([self.sample_rgb, self.sample_alpha], -1).to(torch.float32).clone()

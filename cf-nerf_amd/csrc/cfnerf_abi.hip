@@ -84,6 +84,8 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
     const size_t pbytes = (size_t)m->plan.tab.packed_floats * sizeof(float);
     HIPCHK(hipMalloc(&m->d_packed, pbytes));
     HIPCHK(hipMemset(m->d_packed, 0, pbytes));
+    HIPCHK(hipMalloc(&m->d_packed16, (size_t)m->plan.tab.packed16_elems * 2));
+    HIPCHK(hipMemset(m->d_packed16, 0, (size_t)m->plan.tab.packed16_elems * 2));
     HIPCHK(hipMalloc(&m->d_tab, sizeof(NetTab)));
     HIPCHK(hipMemcpy(m->d_tab, &m->plan.tab, sizeof(NetTab), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
@@ -104,7 +106,7 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
 int cfnerf_model_destroy(cfnerf_model* m) {
     if (!m) return CFNERF_OK;
     hipDeviceSynchronize();
-    hipFree(m->d_packed); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
+    hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
     hipFree(m->d_eps); hipFree(m->d_scratch_ent);
     m->stash.release();
     m->bwd.release();
@@ -117,7 +119,7 @@ int cfnerf_model_destroy(cfnerf_model* m) {
 int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s) {
     if (!m || !flat_params) return fail(CFNERF_E_INVALID, "NULL argument");
     m->flat = flat_params;
-    HIPCHK(launch_pack(flat_params, m->d_packed, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, (hipStream_t)s));
+    HIPCHK(launch_pack(flat_params, m->d_packed, m->d_packed16, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, (hipStream_t)s));
     return CFNERF_OK;
 }
 
@@ -160,7 +162,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     const bool train = flags & CFNERF_F_TRAIN;
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     FwdArgs a{};
-    a.tab = m->d_tab; a.wp = m->d_packed; a.flat = m->flat;
+    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.rays = rays; a.t_vals = t_vals; a.t_rand = z_vals_opt ? nullptr : t_rand; a.z_in = z_vals_opt; a.eps = eps;
     a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
@@ -183,7 +185,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     }
     int grid = 0;
     if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
-    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->n_cu, st, &grid));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, st, &grid));
     if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, st));
@@ -211,11 +213,11 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     hipStream_t st = (hipStream_t)s;
     FwdArgs a{};
-    a.tab = m->d_tab; a.wp = m->d_packed; a.flat = m->flat;
+    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
     int grid = 0;
-    HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->n_cu, st, &grid));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->precision, m->n_cu, st, &grid));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out, st));
     return CFNERF_OK;
@@ -228,6 +230,13 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
     if (N == 0) return CFNERF_OK;
     if (!raw || !z_vals || !rays_d || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
     HIPCHK(launch_composite(raw, z_vals, rays_d, N, S, K, white_bkgd, rgb_map, disp_map, depth_map, weights_opt, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
+int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
+    if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
+    if (mode != 0 && mode != 1) return fail(CFNERF_E_INVALID, "precision mode must be 0 (fp32 MFMA) or 1 (bf16x3 split MFMA)");
+    m->precision = mode;
     return CFNERF_OK;
 }
 

@@ -20,6 +20,7 @@ struct TailArgs {
 struct BwdArgs {
     const NetTab* tab;
     const float* wp;
+    const void* wp16;                                     // split-bf16 operand copies (bf16x3 mode)
     int64_t P;
     int32_t n_wg, nb;
     const float* g_theta;                                 // [P,128]   input (from the tail kernel)

@@ -276,7 +276,7 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int n
 }
 
 // acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials
-template <int NTW>
+template <int NTW, int PREC>
 __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
                                           float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
                                           int rows_valid) {
@@ -298,7 +298,7 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const bool ok = rr + rbase < rows_valid;
                 const float v = (ok && ((mb >> (i * 16 + r)) & 1u)) ? acc[i][j][r] : 0.f;
-                lp[rr * ld] = v;
+                act_store<PREC>(lp + rr * ld, v);
                 if (ok) st_stream(gp + (size_t)rr * gld, v);
                 csum += v;
             }
@@ -307,7 +307,7 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
     }
 }
 
-template <int W>
+template <int W, int PREC>
 __global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
 void bwd_data_kernel(const BwdArgs A) {
     constexpr int LD = act_ld(W);
@@ -319,6 +319,7 @@ void bwd_data_kernel(const BwdArgs A) {
     float* hs = act + kTileM * LD;
     const int tid = threadIdx.x, wave = wave_id();
     const float* __restrict__ wp = A.wp;
+    const __bf16* __restrict__ wp16 = reinterpret_cast<const __bf16*>(A.wp16);
     const int64_t P = A.P;
     float* dbp = A.dbp + (size_t)blockIdx.x * A.nb;           // this workgroup's bias-gradient partials
     const int64_t n_tiles = A.n_tiles;
@@ -336,12 +337,13 @@ void bwd_data_kernel(const BwdArgs A) {
             const int row = idx >> 5, q = idx & 31;
             f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;
             if (row < rows_valid) v = *reinterpret_cast<const f32x4*>(A.g_theta + (p0 + row) * kThetaAll + q * 4);
-            *reinterpret_cast<f32x4*>(act + row * LD + q * 4) = v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD + q * 4 + c, v[c]);
         }
         __syncthreads();
         if (tid < kThetaAll) {                                 // bias gradients of the flow-parameter heads
             float s = 0.f;
-            for (int r = 0; r < kTileM; ++r) s += act[r * LD + tid];
+            for (int r = 0; r < kTileM; ++r) s += act_load<PREC>(act + r * LD + tid);
             dbp[A.db_theta + tid] += s;
         }
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
@@ -352,14 +354,14 @@ void bwd_data_kernel(const BwdArgs A) {
             const bool is_rgb = wave < 2;
             if (is_rgb) {
                 epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
-                mma_seg<1>(acc, T.bt_fr, wave, kWaves, wp, act, LD);
+                mma_any<1, PREC>(acc, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
             } else {
                 epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
-                mma_seg<1>(acc, T.bt_fa, wave - 2, kWaves, wp, act + kThetaRgb, LD);
+                mma_any<1, PREC>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act + kThetaRgb, LD);
             }
             __syncthreads();
-            if (is_rgb) store_bwd<1>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
-            else        store_bwd<1>(acc, e, T.bt_fa.nt, wave - 2, kWaves, hs, HLD, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
+            if (is_rgb) store_bwd<1, PREC>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
+            else        store_bwd<1, PREC>(acc, e, T.bt_fa.nt, wave - 2, kWaves, hs, HLD, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
             __syncthreads();
         }
         // ---- 2. dv = (dh_rgb * R) . relu'(v)
@@ -368,9 +370,9 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTV> e;
             acc_zero(acc);
             epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v);
-            mma_seg<NTV>(acc, T.bt_hr, wave, kWaves, wp, act, LD);
+            mma_any<NTV, PREC>(acc, T.bt_hr, wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
-            store_bwd<NTV>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
+            store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
             __syncthreads();
         }
         // ---- 3. dfeature = dv * V[:, 0:W]        (feature_linear has no activation, MOD:176)
@@ -379,9 +381,9 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat);
-            mma_seg<NTW>(acc, T.bt_vf, wave, kWaves, wp, act, LD);
+            mma_any<NTW, PREC>(acc, T.bt_vf, wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
-            store_bwd<NTW>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
             __syncthreads();
         }
         // ---- 4. dh_{D-1} = (dfeature * F + dh_alpha * A) . relu'(h_{D-1})
@@ -390,10 +392,10 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W);
-            mma_seg<NTW>(acc, T.bt_ft, wave, kWaves, wp, act, LD);
-            mma_seg<NTW>(acc, T.bt_ha, wave, kWaves, wp, hs, HLD);
+            mma_any<NTW, PREC>(acc, T.bt_ft, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC>(acc, T.bt_ha, wave, kWaves, wp, wp16, hs, HLD);
             __syncthreads();
-            store_bwd<NTW>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
             __syncthreads();
         }
         // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
@@ -402,9 +404,9 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
-            mma_seg<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD);
+            mma_any<NTW, PREC>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
-            store_bwd<NTW>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             __syncthreads();
         }
     }
@@ -696,18 +698,19 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // ================================================================================================
 // host side
-static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int n_cu, hipStream_t st, int* grid_out) {
+static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, int n_cu, hipStream_t st, int* grid_out) {
     const size_t lds = bwd_lds_bytes(ht.W, ht.ha_sz);
     const void* fn = nullptr;
+    const bool b16 = prec == PREC_BF16X3;
     switch (ht.W) {
-        case 64: fn = reinterpret_cast<const void*>(bwd_data_kernel<64>); break;
-        case 128: fn = reinterpret_cast<const void*>(bwd_data_kernel<128>); break;
-        case 256: fn = reinterpret_cast<const void*>(bwd_data_kernel<256>); break;
-        case 512: fn = reinterpret_cast<const void*>(bwd_data_kernel<512>); break;
+        case 64: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_F32>); break;
+        case 128: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_F32>); break;
+        case 256: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_F32>); break;
+        case 512: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_F32>); break;
         default: return hipErrorInvalidValue;
     }
-    static size_t lds_set[4] = {0, 0, 0, 0};
-    const int wi = ht.W == 64 ? 0 : ht.W == 128 ? 1 : ht.W == 256 ? 2 : 3;
+    static size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int wi = (ht.W == 64 ? 0 : ht.W == 128 ? 1 : ht.W == 256 ? 2 : 3) + (b16 ? 4 : 0);
     if (lds_set[wi] != lds) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -942,13 +945,13 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     // ---- 2. fused backward-data (+ bias partials)
     BHIP(hipMemsetAsync(B.d_dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
     BwdArgs ba{};
-    ba.tab = m->d_tab; ba.wp = m->d_packed; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
+    ba.tab = m->d_tab; ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = B.d_dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
     if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));
-    BHIP(launch_bwd_data(ba, m->plan.tab, m->n_cu, st, &grid_bd));
+    BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, m->n_cu, st, &grid_bd));
     if (m->timing) BHIP(hipEventRecord(m->ev1[2], st));
 
     // ---- 3. weight gradients + reductions

@@ -107,6 +107,115 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int
     if (NTW > 3 && nvalid == 3) { mma_loop<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
 }
 
+// ================= opt-in split-bf16 ("bf16x3") operand path =====================================
+// An fp32 value v is carried as hi = bf16(v), lo = bf16(v - hi); a product a*b is evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped
+// a_lo*b_lo term is ~2^-18 relative).  LDS activation words hold {hi (low half), lo (high half)}.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+enum { PREC_F32 = 0, PREC_BF16X3 = 1 };
+
+__device__ __forceinline__ unsigned pack_hl(float v) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+template <int PREC>
+__device__ __forceinline__ void act_store(float* p, float v) {
+    if (PREC == PREC_BF16X3) *reinterpret_cast<unsigned*>(p) = pack_hl(v);
+    else *p = v;
+}
+template <int PREC>
+__device__ __forceinline__ float act_load(const float* p) {
+    if (PREC == PREC_BF16X3) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(p);
+        return __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+    }
+    return *p;
+}
+#define CFN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// 8 consecutive {hi,lo} words of one row -> the hi and lo bf16x8 fragments (v_perm_b32 de-interleave)
+__device__ __forceinline__ void split_frag(const u32x4 w0, const u32x4 w1, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+    h[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u); l[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
+    h[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u); l[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
+    h[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u); l[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
+    h[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u); l[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// acc[i][j] += A * B for one operand in the split-bf16 format.  Per 16-k chunk and tile: three MFMAs.
+template <int NTW, int NV>
+__device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* const (&bp)[NTW], const float* a_ptr, int lda, int KC) {
+    // ping-pong: raw A words and B fragments of chunk k+1 are requested before the MFMAs of chunk k
+    u32x4 ra[2][2][2];            // [buf][row tile][half]
+    bf16x8 rb[2][NTW][2];         // [buf][n tile][plane]
+    auto issue = [&](int buf, int kc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4* q = reinterpret_cast<const u32x4*>(a_ptr + i * 32 * lda + kc * 16);
+            ra[buf][i][0] = q[0]; ra[buf][i][1] = q[1];
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { rb[buf][j][0] = bp[j][(size_t)kc * 128]; rb[buf][j][1] = bp[j][(size_t)kc * 128 + 64]; }
+    };
+    auto compute = [&](int buf) {
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split_frag(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = CFN_MFMA16(al[i], rb[buf][j][0], acc[i][j]);      // small terms first
+                acc[i][j] = CFN_MFMA16(ah[i], rb[buf][j][1], acc[i][j]);
+                acc[i][j] = CFN_MFMA16(ah[i], rb[buf][j][0], acc[i][j]);
+            }
+    };
+    issue(0, 0);
+    int kc = 0;
+    for (; kc + 1 < KC; kc += 2) {
+        issue(1, kc + 1);
+        compute(0);
+        issue(0, (kc + 2 < KC) ? kc + 2 : KC - 1);
+        compute(1);
+    }
+    if (kc < KC) compute(0);
+}
+
+template <int NTW>
+__device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const __bf16* __restrict__ wp16,
+                                          const float* lds_a, int lda) {
+    const int lane = lane_id_opaque();
+    const int KC = s.kc16;
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
+    if (nvalid == 0) return;
+    const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5);
+    const bf16x8* bp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) nt = nt0;
+        bp[j] = reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + (size_t)nt * KC * 128 + lane;
+    }
+    if (nvalid == NTW) { mma_loop16<NTW, NTW>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 1 && nvalid == 1) { mma_loop16<NTW, 1>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 2 && nvalid == 2) { mma_loop16<NTW, (NTW > 2 ? 2 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 3 && nvalid == 3) { mma_loop16<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+}
+
+// precision-dispatching wrapper used by the fused kernels
+template <int NTW, int PREC>
+__device__ __forceinline__ void mma_any(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const float* __restrict__ wp,
+                                        const __bf16* __restrict__ wp16, const float* lds_a, int lda) {
+    if (PREC == PREC_BF16X3) mma_seg16<NTW>(acc, s, nt0, nts, wp16, lds_a, lda);
+    else mma_seg<NTW>(acc, s, nt0, nts, wp, lds_a, lda);
+}
+
 // streaming (touch-once) global traffic: keep it from evicting the L2-resident packed weights
 __device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
@@ -118,7 +227,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 
 // Write acc (+bias, activation) to the LDS tile (row-major, stride ld, column offset col0) and
 // optionally to a row-major global stash (stride gld) for rows < rows_valid.
-template <int NTW, int ACT>
+template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                             float* __restrict__ gdst, int gld, int rows_valid,
@@ -141,13 +250,13 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
                 float v = acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
-                lp[rr * ld] = v;
+                act_store<PREC>(lp + rr * ld, v);
                 if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * gld, v);
-                bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
+                if (WANT_BITS) bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
-        if (mbits != nullptr) mbits[nt * 64 + lane] = bits;
+        if (WANT_BITS && mbits != nullptr) mbits[nt * 64 + lane] = bits;
     }
 }
 

@@ -34,26 +34,26 @@ __device__ __forceinline__ float zlin_f(float t, float nearv, float farv, bool l
 }
 
 // positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
-template <int MODE, int LD>
+template <int MODE, int LD, int PREC>
 __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, const float* __restrict__ x, int64_t p0,
                                             int rows_valid, int ic, int icv) {
     const int tid = threadIdx.x;
     if (MODE == 0) {
         for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
             const int row = idx & 63, c = idx >> 6;                 // a wave = one channel of 64 rows: no divergence
-            act[row * LD + c] = (c < ic) ? enc_channel(rowinfo + row * 4, c) : 0.f;
+            act_store<PREC>(act + row * LD + c, (c < ic) ? enc_channel(rowinfo + row * 4, c) : 0.f);
         }
     } else {
         for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
             const int row = idx >> 6, c = idx & 63;
             float v = 0.f;
             if (c < ic && row < rows_valid) v = x[(p0 + row) * (int64_t)(ic + icv) + c];
-            act[row * LD + c] = v;
+            act_store<PREC>(act + row * LD + c, v);
         }
     }
 }
 
-template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN>
+template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
 __global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
 void fused_fwd_kernel(const FwdArgs A) {
     using C = FwdCfg<W>;
@@ -71,6 +71,7 @@ void fused_fwd_kernel(const FwdArgs A) {
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* __restrict__ wp = A.wp;
+    const __bf16* __restrict__ wp16 = reinterpret_cast<const __bf16*>(A.wp16);
     const int S = A.S, K = A.K;
     const int ic = T.ic, icv = T.icv;
     const int chunks_per_ray = (S + kTileM - 1) / kTileM;
@@ -140,12 +141,12 @@ void fused_fwd_kernel(const FwdArgs A) {
             }
 
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
-            encode_tile<MODE, LD>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
+            encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             if (A.st_enc != nullptr) {
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
                     const int row = idx >> 6, c = idx & 63;
-                    if (row < rows_valid) st_stream(A.st_enc + (p0 + row) * 64 + c, act[row * LD + c]);
+                    if (row < rows_valid) st_stream(A.st_enc + (p0 + row) * 64 + c, act_load<PREC>(act + row * LD + c));
                 }
             }
             __syncthreads();
@@ -154,17 +155,17 @@ void fused_fwd_kernel(const FwdArgs A) {
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
                 acc_zero(acc);
-                mma_seg<C::NTW>(acc, T.trunk[l], wave, kWaves, wp, act, LD);
+                mma_any<C::NTW, PREC>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
-                    encode_tile<MODE, LD>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
+                    encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
                     __syncthreads();
-                    mma_seg<C::NTW>(acc, T.skipseg, wave, kWaves, wp, act, LD);
+                    mma_any<C::NTW, PREC>(acc, T.skipseg, wave, kWaves, wp, wp16, act, LD);
                 }
                 __syncthreads();
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
                 __syncthreads();
             }
 
@@ -173,12 +174,12 @@ void fused_fwd_kernel(const FwdArgs A) {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
                 acc_zero(accF); acc_zero(accA);
-                mma_seg<1>(accA, T.ha, wave, kWaves, wp, act, LD);
-                mma_seg<C::NTW>(accF, T.ft, wave, kWaves, wp, act, LD);
+                mma_any<1, PREC>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE>(accA, T.ha, wave, kWaves, wp, hs, HLD, 0,
+                store_tiles<1, ACT_NONE, PREC>(accA, T.ha, wave, kWaves, wp, hs, HLD, 0,
                                          A.st_ha ? A.st_ha + p0 * HA : nullptr, HA, rows_valid);
-                store_tiles<C::NTW, ACT_NONE>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTW, ACT_NONE, PREC>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
             }
@@ -186,31 +187,31 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][C::NTV];
                 acc_zero(acc);
-                mma_seg<C::NTV>(acc, T.vf, wave, kWaves, wp, act, LD);
+                mma_any<C::NTV, PREC>(acc, T.vf, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
                     const int row = idx >> 5, c = idx & 31;
                     float v;
                     if (MODE == 0) v = gdir[c];
                     else v = (c < icv && row < rows_valid) ? A.x[(p0 + row) * (int64_t)(ic + icv) + ic + c] : 0.f;
-                    act[row * LD + c] = v;
+                    act_store<PREC>(act + row * LD + c, v);
                     if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
-                mma_seg<C::NTV>(acc, T.vd, wave, kWaves, wp, act, LD);
+                mma_any<C::NTV, PREC>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTV, ACT_RELU>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
-                                              A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
+                                                    A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 f32x16 acc[2][1];
                 acc_zero(acc);
-                mma_seg<1>(acc, T.hr, wave, kWaves, wp, act, LD);
+                mma_any<1, PREC>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
+                store_tiles<1, ACT_NONE, PREC>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
@@ -220,8 +221,8 @@ void fused_fwd_kernel(const FwdArgs A) {
                 f32x16 acc[2][1];
                 acc_zero(acc);
                 const bool is_rgb = wave < 3;
-                if (is_rgb) mma_seg<1>(acc, T.fr, wave, kWaves, wp, act + W / 2, LD);
-                else        mma_seg<1>(acc, T.fa, 0, kWaves, wp, hs, HLD);
+                if (is_rgb) mma_any<1, PREC>(acc, T.fr, wave, kWaves, wp, wp16, act + W / 2, LD);
+                else        mma_any<1, PREC>(acc, T.fa, 0, kWaves, wp, wp16, hs, HLD);
                 __syncthreads();
                 const SubL s = is_rgb ? T.fr : T.fa;
                 const int nt = is_rgb ? wave : 0;
@@ -549,8 +550,8 @@ hipError_t launch_sample_pdf(const float* z, const float* w, const float* u, int
 
 // ---------------------------------------------------------------------------------------------
 // weight packing: flat state_dict-ordered parameters -> fragment-ordered operands (cfnerf_layout.h)
-__global__ void pack_kernel(const float* __restrict__ flat, float* __restrict__ packed, const PackDesc* __restrict__ descs,
-                            int ndesc, uint32_t total) {
+__global__ void pack_kernel(const float* __restrict__ flat, float* __restrict__ packed, unsigned short* __restrict__ packed16,
+                            const PackDesc* __restrict__ descs, int ndesc, uint32_t total) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int lo = 0, hi = ndesc - 1;
@@ -561,7 +562,14 @@ __global__ void pack_kernel(const float* __restrict__ flat, float* __restrict__ 
     const PackDesc d = descs[lo];
     uint32_t src, dst;
     pack_map(d, idx - d.first_elem, &src, &dst);
-    packed[dst] = flat[src];
+    const float v = flat[src];
+    packed[dst] = v;
+    uint32_t dst16;
+    if (packed16 != nullptr && pack_map16(d, idx - d.first_elem, &dst16)) {      // split-bf16 copy: hi plane, lo plane
+        const unsigned w = pack_hl(v);
+        packed16[dst16] = (unsigned short)(w & 0xffffu);
+        packed16[dst16 + 64 * 8] = (unsigned short)(w >> 16);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -572,9 +580,9 @@ static int max_blocks_per_cu(const void* fn, size_t lds) {
     return nb;
 }
 
-template <int W, int MODE, bool TRAIN>
+template <int W, int MODE, bool TRAIN, int PREC>
 static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hipStream_t st, int* grid_out) {
-    auto fn = fused_fwd_kernel<W, MODE, TRAIN>;
+    auto fn = fused_fwd_kernel<W, MODE, TRAIN, PREC>;
     const size_t lds = fwd_lds_bytes(W, ht.ha_sz);
     static size_t lds_set = 0;
     static int per_cu = 0;
@@ -594,17 +602,21 @@ static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hip
 }
 
 template <int W>
-static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, bool train, int n_cu, hipStream_t st, int* grid_out) {
-    if (mode == 0) return train ? launch_fwd_t<W, 0, true>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false>(a, ht, n_cu, st, grid_out);
-    return train ? launch_fwd_t<W, 1, true>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false>(a, ht, n_cu, st, grid_out);
+static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out) {
+    if (prec == PREC_BF16X3) {
+        if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_BF16X3>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_BF16X3>(a, ht, n_cu, st, grid_out);
+        return train ? launch_fwd_t<W, 1, true, PREC_BF16X3>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_BF16X3>(a, ht, n_cu, st, grid_out);
+    }
+    if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_F32>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_F32>(a, ht, n_cu, st, grid_out);
+    return train ? launch_fwd_t<W, 1, true, PREC_F32>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_F32>(a, ht, n_cu, st, grid_out);
 }
 
-hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int n_cu, hipStream_t st, int* grid_out) {
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out) {
     switch (ht.W) {
-        case 64: return launch_fwd_w<64>(a, ht, mode, train, n_cu, st, grid_out);
-        case 128: return launch_fwd_w<128>(a, ht, mode, train, n_cu, st, grid_out);
-        case 256: return launch_fwd_w<256>(a, ht, mode, train, n_cu, st, grid_out);
-        case 512: return launch_fwd_w<512>(a, ht, mode, train, n_cu, st, grid_out);
+        case 64: return launch_fwd_w<64>(a, ht, mode, train, prec, n_cu, st, grid_out);
+        case 128: return launch_fwd_w<128>(a, ht, mode, train, prec, n_cu, st, grid_out);
+        case 256: return launch_fwd_w<256>(a, ht, mode, train, prec, n_cu, st, grid_out);
+        case 512: return launch_fwd_w<512>(a, ht, mode, train, prec, n_cu, st, grid_out);
     }
     return hipErrorInvalidValue;
 }
@@ -635,9 +647,9 @@ hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int
     return hipGetLastError();
 }
 
-hipError_t launch_pack(const float* flat, float* packed, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st) {
+hipError_t launch_pack(const float* flat, float* packed, void* packed16, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st) {
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, flat, packed, descs, ndesc, total);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, flat, packed, reinterpret_cast<unsigned short*>(packed16), descs, ndesc, total);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ struct RaysC2W { float m[12]; };
 struct FwdArgs {
     const NetTab* tab;        // device copy of the operand table
     const float* wp;          // packed operands
+    const void* wp16;         // split-bf16 copies of the operands (bf16x3 mode)
     const float* flat;        // flat parameters (base-Gaussian mean/std live at [0,8))
     const float* rays;        // [N,11]         (ray mode)
     const float* t_vals;      // [S]
@@ -34,7 +35,7 @@ struct FwdArgs {
     int64_t n_tiles;                     // tiles of the launch (rays * chunks per ray)
 };
 
-hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int n_cu, hipStream_t st, int* grid_out);
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out);
 int fused_fwd_max_grid(int W, int ha, int n_cu);
 hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
                                    double count, float* out, hipStream_t st);
@@ -43,6 +44,6 @@ hipError_t launch_composite(const float* raw, const float* z, const float* d, in
 hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
                              int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out, hipStream_t st);
 hipError_t launch_sample_pdf(const float* z, const float* w, const float* u, int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st);
-hipError_t launch_pack(const float* flat, float* packed, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
+hipError_t launch_pack(const float* flat, float* packed, void* packed16, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
 
 }  // namespace cfnerf

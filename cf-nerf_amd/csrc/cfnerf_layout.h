@@ -94,6 +94,12 @@ struct SubL {
     uint32_t b_off;      // floats, padded bias (nt*32 entries); 0xffffffff = none
     uint16_t kc;         // k chunks of 8
     uint16_t nt;         // n tiles of 32
+    // split-bf16 copy of the same operand for v_mfma_f32_32x32x16_bf16 (opt-in "bf16x3" mode):
+    //   packed16[w16_off + (((nt*kc16 + c)*2 + plane)*64 + lane)*8 + e] = bf16 part `plane` (0 hi, 1 lo) of
+    //   M[nt*32 + (lane&31)][c*16 + 8*(lane>>5) + e]
+    uint32_t w16_off;    // in bf16 elements
+    uint16_t kc16;       // k chunks of 16
+    uint16_t pad_;
 };
 
 // theta (flow-parameter) column map inside a tile row: rgb heads [0,96), alpha heads [96,128)
@@ -118,6 +124,7 @@ struct NetTab {
     SubL bt_trunk[kMaxDepth];// bt_trunk[l]: dh_l -> dh_{l-1}   (l >= 1; skip layer: h segment only)
     int32_t D, W, skip, ic, icv, ha_sz, hr_sz, F;
     uint32_t packed_floats;
+    uint32_t packed16_elems;
 };
 
 // source piece of a packed operand (device-visible POD)
@@ -132,6 +139,8 @@ struct PackDesc {
     uint32_t red_off;    // offset added to the REDUCTION index inside the operand
     uint32_t transpose;  // 0: out = row, red = col (forward) ; 1: out = col, red = row (backward-data)
     uint32_t first_elem; // prefix sum of element counts (for the flat thread -> desc search)
+    uint32_t dst16_off;  // bf16-copy offset of the operand (elements)
+    uint32_t kc16;       // k16-chunk count of the bf16 copy
 };
 
 #if defined(__HIPCC__)
@@ -154,6 +163,17 @@ CFN_HD inline void pack_map(const PackDesc& d, uint32_t local, uint32_t* src, ui
     *dst = d.dst_off + ((nt * d.kc + kc) * 64 + lane) * 4 + c;
 }
 
+// bf16-copy destination of the same element (hi plane; the lo plane is 64*8 elements further)
+CFN_HD inline bool pack_map16(const PackDesc& d, uint32_t local, uint32_t* dst16) {
+    if (d.n_cols == 0) return false;
+    const uint32_t row = local / d.n_cols, col = local - row * d.n_cols;
+    const uint32_t o = (d.transpose ? col : row) + d.out_off;
+    const uint32_t r = (d.transpose ? row : col) + d.red_off;
+    const uint32_t nt = o >> 5, lane = (o & 31) + 32 * ((r & 15) >> 3), c = r >> 4, e = r & 7;
+    *dst16 = d.dst16_off + (((nt * d.kc16 + c) * 2) * 64 + lane) * 8 + e;
+    return true;
+}
+
 struct PackPlan {
     NetTab tab;
     std::vector<PackDesc> descs;
@@ -166,11 +186,13 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
     std::memset(&T, 0, sizeof(T));
     const int W = c.netwidth, D = c.netdepth, ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), F = c.n_flows;
     T.D = D; T.W = W; T.skip = D / 2; T.ic = ic; T.icv = icv; T.ha_sz = c.h_alpha_size; T.hr_sz = c.h_rgb_size; T.F = F;
-    uint32_t cur = 0;
+    uint32_t cur = 0, cur16 = 0;
     auto alloc_op = [&](int n_out, int k_red, bool bias) {
         SubL s;
         s.nt = (uint16_t)(pad_to(n_out, 32) / 32);
         s.kc = (uint16_t)(pad_to(k_red, 8) / 8);
+        s.kc16 = (uint16_t)(pad_to(k_red, 16) / 16); s.pad_ = 0;
+        s.w16_off = cur16; cur16 += (uint32_t)s.nt * s.kc16 * 2 * 64 * 8;
         s.w_off = cur; cur += (uint32_t)s.nt * s.kc * 256;
         if (bias) { s.b_off = cur; cur += (uint32_t)s.nt * 32; } else s.b_off = 0xffffffffu;
         return s;
@@ -180,6 +202,7 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
         PackDesc d{};
         d.src_off = (uint32_t)(e->off + col0); d.src_ld = (uint32_t)e->cols; d.n_rows = (uint32_t)e->rows;
         d.n_cols = (uint32_t)ncols; d.dst_off = s.w_off; d.kc = s.kc; d.out_off = out_off; d.red_off = red_off;
+        d.dst16_off = s.w16_off; d.kc16 = s.kc16;
         d.transpose = transpose ? 1 : 0; d.first_elem = P.total_elems;
         P.total_elems += d.n_rows * d.n_cols;
         P.descs.push_back(d);
@@ -264,6 +287,7 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
         piece(T.bt_trunk[l], kw, (l - 1 == T.skip) ? ic : 0, W, 0, 0, true);
     }
     T.packed_floats = cur;
+    T.packed16_elems = cur16;
     return P;
 }
 
