@@ -197,7 +197,7 @@ def main():
             dta = float(t.item())
         net.set_precision("fp32")
         alt = {"precision": "bf16x3 (opt-in): fp32 operands carried as hi+lo bf16, product = hi*hi + hi*lo + lo*hi on "
-                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward + backward-data (weight-gradient GEMMs stay fp32); "
+                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward, backward-data and the large weight-gradient GEMMs; "
                             "held to the same parity tolerances (tests/test_hip_bf16x3.py)",
                "value": N_RAND * world * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
                "fwd_launch_ms": alt_fwd_ms}

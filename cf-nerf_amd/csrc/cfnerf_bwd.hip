@@ -448,6 +448,7 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 constexpr int kDwRows = 32;                   // points per LDS stage
 constexpr int kDwSmallGroup = 4;              // dw_small_kernel: point-pairs per register group (2 groups in flight)
 constexpr int kDwThreads = 512;
+template <int PREC>
 __global__ __launch_bounds__(kDwThreads, 2)
 void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
                    const float* __restrict__ zeros) {
@@ -481,8 +482,18 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<f32x4*>(As + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc)) = ra[q];
-            *reinterpret_cast<f32x4*>(Bs + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc)) = rb[q];
+            float* pa = As + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc);
+            float* pb2 = Bs + ((buf * kDwRows + lrow + 8 * q) * 256 + 4 * lc);
+            if (PREC == PREC_BF16X3) {          // operands enter LDS as {hi,lo} bf16 words
+                u32x4 wa, wb;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { wa[c] = pack_hl(ra[q][c]); wb[c] = pack_hl(rb[q][c]); }
+                *reinterpret_cast<u32x4*>(pa) = wa;
+                *reinterpret_cast<u32x4*>(pb2) = wb;
+            } else {
+                *reinterpret_cast<f32x4*>(pa) = ra[q];
+                *reinterpret_cast<f32x4*>(pb2) = rb[q];
+            }
         }
     };
     f32x16 acc[4][2];
@@ -506,6 +517,48 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         if (more) gload(p + kDwRows);
         __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
         if (active) {
+            if (PREC == PREC_BF16X3) {
+                // two 16-point chunks per stage; lane (i, kk) gathers points 8*kk .. 8*kk+7 of its columns
+#pragma unroll
+                for (int c16 = 0; c16 < kDwRows / 16; ++c16) {
+                    const float* ar = As + (buf * kDwRows + c16 * 16 + 8 * kk) * 256 + 128 * wn + 4 * i;
+                    const float* br = Bs + (buf * kDwRows + c16 * 16 + 8 * kk) * 256 + 64 * wk + 2 * i;
+                    u32x4 wa[8];
+                    unsigned wb0[8], wb1[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        wa[e] = *reinterpret_cast<const u32x4*>(ar + e * 256);
+                        const f32x2 t2 = *reinterpret_cast<const f32x2*>(br + e * 256);
+                        wb0[e] = __float_as_uint(t2[0]); wb1[e] = __float_as_uint(t2[1]);
+                    }
+                    bf16x8 bh[2], bl[2];
+                    {
+                        u32x4 h, l;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { h[q] = __builtin_amdgcn_perm(wb0[2 * q + 1], wb0[2 * q], 0x05040100u); l[q] = __builtin_amdgcn_perm(wb0[2 * q + 1], wb0[2 * q], 0x07060302u); }
+                        bh[0] = __builtin_bit_cast(bf16x8, h); bl[0] = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { h[q] = __builtin_amdgcn_perm(wb1[2 * q + 1], wb1[2 * q], 0x05040100u); l[q] = __builtin_amdgcn_perm(wb1[2 * q + 1], wb1[2 * q], 0x07060302u); }
+                        bh[1] = __builtin_bit_cast(bf16x8, h); bl[1] = __builtin_bit_cast(bf16x8, l);
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        u32x4 h, l;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            h[q] = __builtin_amdgcn_perm(wa[2 * q + 1][tn], wa[2 * q][tn], 0x05040100u);
+                            l[q] = __builtin_amdgcn_perm(wa[2 * q + 1][tn], wa[2 * q][tn], 0x07060302u);
+                        }
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, h), al = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+                        for (int tk = 0; tk < 2; ++tk) {
+                            acc[tn][tk] = CFN_MFMA16(al, bh[tk], acc[tn][tk]);
+                            acc[tn][tk] = CFN_MFMA16(ah, bl[tk], acc[tn][tk]);
+                            acc[tn][tk] = CFN_MFMA16(ah, bh[tk], acc[tn][tk]);
+                        }
+                    }
+                }
+            } else {
             const float* ar = a_rd + buf * kDwRows * 256;
             const float* br = b_rd + buf * kDwRows * 256;
 #pragma unroll 4
@@ -517,6 +570,7 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
                     acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
                     acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
                 }
+            }
             }
         }
         __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
@@ -926,7 +980,9 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         B.tiles_for = q.h; B.tiles_P = P;
         static bool attr_set = false;
         if (!attr_set) {
-            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(4 * kDwRows * 256 * sizeof(float))));
+            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(4 * kDwRows * 256 * sizeof(float))));
             attr_set = true;
         }
@@ -957,8 +1013,12 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     // ---- 3. weight gradients + reductions
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
     if (B.n_blocks > 0) {
-        hipLaunchKernelGGL(dw_big_kernel, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
-                           B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
+        if (m->precision == PREC_BF16X3)
+            hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
+                               B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
+        else
+            hipLaunchKernelGGL(dw_big_kernel<PREC_F32>, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
+                               B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
         BHIP(hipGetLastError());
     }
     if (B.n_blocks_small > 0) {

@@ -152,8 +152,8 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
 /* OPT-IN arithmetic mode of the fused forward's dense layers.  0 (default): exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32).  1: "bf16x3" - every fp32 operand is carried as hi + lo bf16 and a product is evaluated
  * as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo*lo term is ~2^-18
- * relative); it is held to the SAME parity tolerances by tests/test_hip_bf16x3.py.  Applies to the fused forward
- * and the backward-data kernel; the weight-gradient GEMMs stay exact fp32.                                      */
+ * relative); it is held to the SAME parity tolerances by tests/test_hip_bf16x3.py.  Applies to the fused forward,
+ * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).                */
 int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 
 /* bytes currently held by the model's stash / workspaces (diagnostics) */
