@@ -39,7 +39,7 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // returns nullptr when valid, else the reason
 inline const char* validate_cfg(const cfnerf_cfg& c) {
-    if (c.netdepth < 2 || c.netdepth > kMaxDepth) return "netdepth must be in [2,16]";
+    if (c.netdepth < 3 || c.netdepth > kMaxDepth) return "netdepth must be in [3,16] (the skip concat after layer netdepth/2 must feed a trunk layer)";
     if (c.netwidth != 64 && c.netwidth != 128 && c.netwidth != 256 && c.netwidth != 512)
         return "netwidth must be 64, 128, 256 or 512";
     if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";

@@ -45,7 +45,7 @@ def test_flat_layout_is_state_dict_order(W, ha, hr):
 def test_unsupported_configs_are_rejected_loudly():
     lib = L.lib()
     for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 3), L.Cfg(8, 256, 11, 4, 32, 64, 4),
-                L.Cfg(1, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4)):
+                L.Cfg(2, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4)):
         assert lib.cfnerf_param_count(C.byref(bad)) < 0
         assert lib.cfnerf_last_error() != b""
 

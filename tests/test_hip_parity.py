@@ -276,3 +276,39 @@ def test_hierarchical_extension_vs_own_restatement(perturb):
     close(ret["depth_map"], r["depth_map"], atol=1e-4, rtol=1e-3, what="fine depth")
     with pytest.raises(NotImplementedError):                                            # default stays reference-faithful
         cfnerf_amd.render_rays(packed.to(DEV), N_samples=S, N_importance=Ni, perturb=0., **kw)
+
+
+# ---------------------------------------------------------------- shapes off the beaten path
+@pytest.mark.parametrize("D,W,K,N,S", [(6, 128, 2, 5, 128), (4, 64, 64, 3, 128), (8, 256, 7, 1, 128), (8, 64, 3, 4, 300), (3, 64, 2, 6, 33)])
+def test_generic_depth_k_limit_single_ray_long_tables(D, W, K, N, S):
+    """netdepth != 8 (skip at D/2, RUN:327), K at the supported maximum, one ray, tables longer / shorter than a tile."""
+    cfg = O.OracleCfg(netdepth=D, netwidth=W, K_samples=K)
+    _, kw_train, _, model, p, _ = build_model(cfg, 700 + D + K, netdepth=D)
+    rng = np.random.default_rng(D * 100 + K)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    tv = O.t_vals_table() if S == 128 else torch.sort(torch.tensor(rng.uniform(0, 1, S), dtype=torch.float32)).values
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    kw = {k: v for k, v in kw_train.items() if k != "use_viewdirs"}
+    kw["N_samples"] = S
+    with torch.no_grad():
+        ret = cfnerf_amd.render_rays(packed.to(DEV), t_vals=tv, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, retweights=True, **kw)
+    r = O.render_rays(p, packed, cfg, ea, er, True, t_rand=t_rand, t_vals=tv)
+    close(ret["raw"], r["raw"], what="raw")
+    close(ret["rgb_map"], r["rgb_map"], what="rgb_map")
+    close(ret["weights"], r["weights"], what="weights")
+    close(ret["loss_entropy"].mean(), r["loss_entropy"], what="entropy")
+
+
+def test_k_above_the_limit_and_bad_widths_are_rejected():
+    import argparse
+    from util_hip import make_args
+    cfg = O.OracleCfg(netwidth=64, K_samples=65)
+    args = make_args(cfg)
+    kw, _, _, _, _ = cfnerf_amd.create_nerf(args)
+    with pytest.raises(RuntimeError, match="K_samples"):
+        cfnerf_amd.render_rays(torch.zeros(2, 11, device=DEV) + 0.5, **{k: v for k, v in kw.items() if k != "use_viewdirs"})
+    with pytest.raises(RuntimeError, match="netwidth"):
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=96)))

@@ -196,3 +196,26 @@ def test_training_reduces_the_loss():
     assert np.isfinite(losses).all()
     # the K-sample NLL is noisy step to step; the MSE of the K-mean prediction against a FIXED target batch must fall
     assert losses[-20:, 2].mean() < 0.9 * losses[:20, 2].mean(), (losses[:20, 2].mean(), losses[-20:, 2].mean())
+
+
+@pytest.mark.parametrize("D,W,K,N", [(6, 128, 3, 20), (4, 64, 5, 12)])
+def test_gradients_generic_depth(D, W, K, N):
+    cfg = O.OracleCfg(netdepth=D, netwidth=W, K_samples=K)
+    _, kw_train, _, model, p, _ = build_model(cfg, 900 + D, netdepth=D)
+    net = model.module
+    rng = np.random.default_rng(D)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    tr = TR.Trainer(net, beta1=0.02)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, 0.02)
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    for key, (off, cnt) in net.layout.items():
+        if grads[key] is None:
+            assert not grad[off:off + cnt].any()
+        else:
+            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
