@@ -93,7 +93,6 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
     m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
     HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
     HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
-    HIPCHK(hipMalloc(&m->d_scratch_ent, sizeof(float)));
     for (int i = 0; i < kNumTimers; ++i) {
         HIPCHK(hipEventCreate(&m->ev0[i]));
         HIPCHK(hipEventCreate(&m->ev1[i]));
@@ -107,10 +106,9 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     if (!m) return CFNERF_OK;
     hipDeviceSynchronize();
     hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
-    hipFree(m->d_eps); hipFree(m->d_scratch_ent);
+    hipFree(m->d_eps);
     m->stash.release();
     m->bwd.release();
-    for (void* p : m->owned) hipFree(p);
     for (int i = 0; i < kNumTimers; ++i) { hipEventDestroy(m->ev0[i]); hipEventDestroy(m->ev1[i]); }
     delete m;
     return CFNERF_OK;
@@ -177,8 +175,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         a.st_mbits = reinterpret_cast<uint32_t*>(q.mbits);
         q.n_tiles = N * (int64_t)((S + kTileM - 1) / kTileM);
         a.n_tiles = q.n_tiles;
-        if (!a.raw) a.raw = q.raw;
-        q.raw_used = a.raw;
+        a.raw = q.raw;                       // the backward reads the model's OWN copy: the caller may drop its tensor
+        q.raw_used = q.raw;
         HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
         q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true;
@@ -187,6 +185,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, st, &grid));
     if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
+    if ((flags & CFNERF_F_STASH) && raw_opt)
+        HIPCHK(hipMemcpyAsync(raw_opt, m->stash.raw, (size_t)a.P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, st));
     return CFNERF_OK;

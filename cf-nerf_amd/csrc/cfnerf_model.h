@@ -37,19 +37,17 @@ struct Stash {
     float *g_v = nullptr;       // [P,W/2]  pre-activation gradient of the views layer
     float *g_feat = nullptr;    // [P,W]
     float *g_h = nullptr;       // [D,P,W]  pre-activation gradients of the trunk layers
-    float *partials = nullptr;  // split-K partial weight gradients
     const float* raw_used = nullptr;
     int64_t cap_P = 0, cap_N = 0; int cap_K = 0;
     int64_t N = 0; int S = 0, K = 0, flags = 0;
     bool valid = false;
     size_t bytes = 0;
-    size_t partial_floats = 0;
 
     void release() {
         float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays, &at, &dbp, &gms, &mbits,
-                         &g_theta, &g_hr, &g_ha, &g_v, &g_feat, &g_h, &partials};
+                         &g_theta, &g_hr, &g_ha, &g_v, &g_feat, &g_h};
         for (float** p : all) { if (*p) hipFree(*p); *p = nullptr; }
-        cap_P = cap_N = 0; cap_K = 0; bytes = 0; valid = false; partial_floats = 0;
+        cap_P = cap_N = 0; cap_K = 0; bytes = 0; valid = false;
     }
 
     int ensure(const cfnerf_cfg& c, int64_t n, int s, int k) {
@@ -91,10 +89,8 @@ struct cfnerf_model {
     const float* flat = nullptr;          // caller-owned flat parameter buffer (last set_params)
     float* d_ent_partials = nullptr; int ent_cap = 0;
     float* d_eps = nullptr;               // eps of the stashed forward
-    float* d_scratch_ent = nullptr;
     cfnerf::Stash stash;
     cfnerf::BwdPlan bwd;
-    std::vector<void*> owned;             // misc device allocations freed at destroy
     bool timing = false;
     hipEvent_t ev0[cfnerf::kNumTimers]{}, ev1[cfnerf::kNumTimers]{};
     size_t ws_bytes = 0;

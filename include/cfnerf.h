@@ -56,7 +56,8 @@ enum {
     CFNERF_F_TRAIN      = 1 << 0,       /* train branch of NeRF_Flows.forward (MOD:225-291): log-dets + entropy */
     CFNERF_F_LINDISP    = 1 << 1,       /* render_rays(lindisp=True)  RUN:513-514 */
     CFNERF_F_WHITE_BKGD = 1 << 2,       /* raw2outputs(white_bkgd=True) RUN:451-452 */
-    CFNERF_F_STASH      = 1 << 3        /* keep activations for cfnerf_render_bwd (implies TRAIN) */
+    CFNERF_F_STASH      = 1 << 3        /* keep activations for cfnerf_render_bwd (implies TRAIN); ONE stash per model: a later
+                                           STASH forward replaces it */
 };
 
 int         cfnerf_version(void);
