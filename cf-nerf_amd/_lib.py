@@ -29,7 +29,7 @@ _SIGS = {
                                     C.c_float, C.c_float, _P, _P]),
     "cfnerf_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P]),
-    "cfnerf_sample_pdf": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "cfnerf_sample_pdf": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
     "cfnerf_network_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
     "cfnerf_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "cfnerf_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_int64, _P, _P, _P]),

@@ -548,16 +548,9 @@ def _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is
                                       L.stream()), "cfnerf_render_fwd")
         return rgb, disp, depth, wts, ent
     rgb0, disp0, depth0, w0, _ = launch(S, None, True)
-    # the coarse depths are needed by the resampler: recompute them with the same formula on the device tensors
-    near, far = rays[:, 6:7], rays[:, 7:8]
-    z = near * (1. - tv) + far * tv if not lindisp else 1. / (1. / near * (1. - tv) + 1. / far * tv)
-    z = z.expand(N, S)
-    if tr is not None:
-        mids = .5 * (z[..., 1:] + z[..., :-1])
-        z = torch.cat([z[..., :1], mids], -1) + (torch.cat([mids, z[..., -1:]], -1) - torch.cat([z[..., :1], mids], -1)) * tr
-    z = z.contiguous()
     z_all = torch.empty(N, S + N_importance, device=dev)
-    L.check(lib.cfnerf_sample_pdf(L.ptr(z), L.ptr(w0), L.ptr(u), N, S, K, N_importance, L.ptr(z_all), L.stream()), "cfnerf_sample_pdf")
+    L.check(lib.cfnerf_sample_pdf(L.ptr(rays), L.ptr(tv), L.ptr(tr), flags, L.ptr(w0), L.ptr(u), N, S, K, N_importance, L.ptr(z_all),
+                                  L.stream()), "cfnerf_sample_pdf")
     rgb, disp, depth, _, ent = launch(S + N_importance, z_all, False)
     ret = {'rgb_map': rgb, 'disp_map': disp, 'depth_map': depth, 'rgb0': rgb0, 'disp0': disp0, 'depth0': depth0, 'z_vals': z_all}
     if is_train:

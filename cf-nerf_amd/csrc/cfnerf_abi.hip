@@ -192,13 +192,13 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     return CFNERF_OK;
 }
 
-int cfnerf_sample_pdf(const float* z_vals, const float* weights, const float* u, int64_t N, int S, int K, int N_importance,
-                      float* z_out, cfnerf_stream s) {
+int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* weights, const float* u,
+                      int64_t N, int S, int K, int N_importance, float* z_out, cfnerf_stream s) {
     if (N < 0 || S < 3 || K < 1 || N_importance < 1) return fail(CFNERF_E_INVALID, "bad N/S/K/N_importance (S >= 3)");
     if (S + N_importance > 1024) return fail(CFNERF_E_UNSUPPORTED, "S + N_importance must be <= 1024");
     if (N == 0) return CFNERF_OK;
-    if (!z_vals || !weights || !u || !z_out) return fail(CFNERF_E_INVALID, "NULL argument");
-    HIPCHK(launch_sample_pdf(z_vals, weights, u, N, S, K, N_importance, z_out, (hipStream_t)s));
+    if (!rays || !t_vals || !weights || !u || !z_out) return fail(CFNERF_E_INVALID, "NULL argument");
+    HIPCHK(launch_sample_pdf(rays, t_vals, t_rand, flags, weights, u, N, S, K, N_importance, z_out, (hipStream_t)s));
     return CFNERF_OK;
 }
 

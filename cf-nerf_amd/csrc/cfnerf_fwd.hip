@@ -487,13 +487,28 @@ __global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int u
 // reference itself has no second pass).  One wave per ray.
 constexpr int kPdfMax = 1024;            // S + N_importance
 __global__ __launch_bounds__(64)
-void sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ weights, const float* __restrict__ u,
-                       int64_t N, int S, int K, int Ni, float* __restrict__ z_out) {
-    __shared__ float cdf[kPdfMax], bins[kPdfMax], zall[kPdfMax];
+void sample_pdf_kernel(const float* __restrict__ rays, const float* __restrict__ t_vals, const float* __restrict__ t_rand, int flags,
+                       const float* __restrict__ weights, const float* __restrict__ u, int64_t N, int S, int K, int Ni,
+                       float* __restrict__ z_out) {
+    __shared__ float cdf[kPdfMax], bins[kPdfMax], zall[kPdfMax], zr[kPdfMax];
     const int lane = lane_id();
     const int64_t n = blockIdx.x;
     if (n >= N) return;
-    const float* zr = z_vals + n * (int64_t)S;
+    {   // coarse depths, the same arithmetic as the fused forward (RUN:510-532)
+        const float nearv = rays[n * 11 + 6], farv = rays[n * 11 + 7];
+        const bool lind = (flags & CFNERF_F_LINDISP) != 0;
+        for (int s = lane; s < S; s += 64) {
+            const float zc = zlin_f(t_vals[s], nearv, farv, lind);
+            float zv = zc;
+            if (t_rand != nullptr) {
+                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(t_vals[s + 1], nearv, farv, lind) + zc);
+                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(t_vals[s - 1], nearv, farv, lind));
+                zv = lower + (upper - lower) * t_rand[n * (int64_t)S + s];
+            }
+            zr[s] = zv;
+        }
+    }
+    __syncthreads();
     const int nb = S - 1;                 // bins = mids of consecutive depths; cdf has nb entries (first = 0)
     const int nw = S - 2;                 // weights[..., 1:-1]
     for (int j = lane; j < nb; j += 64) bins[j] = 0.5f * (zr[j + 1] + zr[j]);
@@ -543,8 +558,9 @@ void sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict
     }
 }
 
-hipError_t launch_sample_pdf(const float* z, const float* w, const float* u, int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st) {
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(64), 0, st, z, w, u, N, S, K, Ni, z_out);
+hipError_t launch_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* w, const float* u,
+                             int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st) {
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(64), 0, st, rays, t_vals, t_rand, flags, w, u, N, S, K, Ni, z_out);
     return hipGetLastError();
 }
 

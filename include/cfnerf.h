@@ -114,9 +114,10 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
 /* EXTENSION (not in the reference, whose N_importance / network_fine are dead parameters, RUN:467-468; the
  * semantics restated are those of the reference's upstream, yenchenlin/nerf-pytorch sample_pdf): inverse-CDF
  * resampling of N_importance depths per ray from the K-mean of the coarse weights, merged and sorted with the
- * coarse depths.  z_vals [N,S], weights [N,S,K], u [N,N_importance] in [0,1] -> z_out [N,S+N_importance].      */
-int cfnerf_sample_pdf(const float* z_vals, const float* weights, const float* u, int64_t N, int S, int K,
-                      int N_importance, float* z_out, cfnerf_stream s);
+ * coarse depths.  The coarse depths are recomputed from (rays, t_vals, t_rand, LINDISP flag) exactly as
+ * cfnerf_render_fwd samples them.  weights [N,S,K], u [N,N_importance] in [0,1] -> z_out [N,S+N_importance].    */
+int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* weights,
+                      const float* u, int64_t N, int S, int K, int N_importance, float* z_out, cfnerf_stream s);
 
 /* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]
  * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].                   */
