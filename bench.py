@@ -44,13 +44,13 @@ def synth_batch(rank, n, device):
     return rays.to(device), target.to(device), (H, Wd, focal)
 
 
-def cpu_baseline(mode, budget_s=20.0):
+def cpu_baseline(mode, budget_s=30.0):
     """The CPU oracle (op-for-op PyTorch-CPU restatement of the reference, oracle/) timed on this box's
     host cores on a bounded sample of the same workload.  The thread count is swept (all usable
     cores is NOT the fastest for these GEMM sizes) and the best setting is reported with its count."""
     from oracle import cfnerf_oracle as O
     from util_hip import fern_rays
-    n_rays = 64 if mode == "train" else 256
+    n_rays = N_RAND                              # the full per-GPU workload of one step
     cfg = O.OracleCfg(netwidth=W, K_samples=K)
     p = O.make_params(cfg, 0)
     rng = np.random.default_rng(5)
