@@ -219,3 +219,39 @@ def test_gradients_generic_depth(D, W, K, N):
             assert not grad[off:off + cnt].any()
         else:
             grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
+
+
+def test_depth_gradient_path_matches_oracle():
+    """The depth-supervision term of the reference (RUN:1020,1052-1054: mse of the K-mean depth) reaches the kernels
+    through d(depth_map); checked through the autograd path against the oracle's autograd."""
+    cfg = O.OracleCfg(netwidth=64, K_samples=3)
+    _, kw_train, _, model, p, optimizer = build_model(cfg, 31, white_bkgd=True)
+    net = model.module
+    rng = np.random.default_rng(9)
+    N, K = 24, 3
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    target_depth = torch.tensor(rng.uniform(0.2, 0.8, (N,)), dtype=torch.float32)
+
+    def loss_of(rgbs, depth, ent, dev):
+        return (torch.mean((rgbs.mean(-1) - target.to(dev)) ** 2) + 0.1 * torch.mean((depth.mean(-1) - target_depth.to(dev)) ** 2)
+                + 0.01 * ent)
+    rgbs, disp, depth, extras = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    loss = loss_of(rgbs, depth, extras["loss_entropy"].mean(), DEV)
+    optimizer.zero_grad()
+    loss.backward()
+    g_hip = net.flat.grad.cpu()
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    r = O.render_rays(q, packed, cfg, ea, er, True, t_rand, white_bkgd=True)
+    loss_o = loss_of(r["rgb_map"], r["depth_map"], r["loss_entropy"], "cpu")
+    loss_o.backward()
+    close(loss, loss_o, atol=1e-6, rtol=1e-5, what="loss")
+    for key, (off, cnt) in net.layout.items():
+        if q[key].grad is None:
+            assert not g_hip[off:off + cnt].any()
+        else:
+            grad_close(g_hip[off:off + cnt].reshape(q[key].grad.shape), q[key].grad.numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
