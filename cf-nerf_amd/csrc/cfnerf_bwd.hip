@@ -354,10 +354,10 @@ void bwd_data_kernel(const BwdArgs A) {
             const bool is_rgb = wave < 2;
             if (is_rgb) {
                 epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
-                mma_any<1, PREC>(acc, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
             } else {
                 epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
-                mma_any<1, PREC>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act + kThetaRgb, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act + kThetaRgb, LD);
             }
             __syncthreads();
             if (is_rgb) store_bwd<1, PREC>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
@@ -370,7 +370,7 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTV> e;
             acc_zero(acc);
             epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v);
-            mma_any<NTV, PREC>(acc, T.bt_hr, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_hr, wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
             __syncthreads();
@@ -381,7 +381,7 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat);
-            mma_any<NTW, PREC>(acc, T.bt_vf, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_vf, wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
             __syncthreads();
@@ -392,8 +392,8 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W);
-            mma_any<NTW, PREC>(acc, T.bt_ft, wave, kWaves, wp, wp16, act, LD);
-            mma_any<NTW, PREC>(acc, T.bt_ha, wave, kWaves, wp, wp16, hs, HLD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_ft, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_ha, wave, kWaves, wp, wp16, hs, HLD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
             __syncthreads();
@@ -404,7 +404,7 @@ void bwd_data_kernel(const BwdArgs A) {
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
-            mma_any<NTW, PREC>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             __syncthreads();

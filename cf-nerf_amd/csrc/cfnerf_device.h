@@ -147,21 +147,24 @@ __device__ __forceinline__ void split_frag(const u32x4 w0, const u32x4 w1, bf16x
 }
 
 // acc[i][j] += A * B for one operand in the split-bf16 format.  Per 16-k chunk and tile: three MFMAs.
-template <int NTW, int NV>
+// A chunk is only 12*NV MFMAs (~400-800 cycles) - less than the L2 latency - so the B fragments (global) run
+// kPre16 chunks ahead in a rotating register ring; the A words (LDS, short latency) one chunk ahead.
+template <int NTW, int NV, int kPre16>
 __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* const (&bp)[NTW], const float* a_ptr, int lda, int KC) {
-    // ping-pong: raw A words and B fragments of chunk k+1 are requested before the MFMAs of chunk k
+    bf16x8 rb[kPre16][NTW][2];    // [ring slot][n tile][plane]
     u32x4 ra[2][2][2];            // [buf][row tile][half]
-    bf16x8 rb[2][NTW][2];         // [buf][n tile][plane]
-    auto issue = [&](int buf, int kc) {
+    auto issue_b = [&](int slot, int kc) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { rb[slot][j][0] = bp[j][(size_t)kc * 128]; rb[slot][j][1] = bp[j][(size_t)kc * 128 + 64]; }
+    };
+    auto issue_a = [&](int buf, int kc) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const u32x4* q = reinterpret_cast<const u32x4*>(a_ptr + i * 32 * lda + kc * 16);
             ra[buf][i][0] = q[0]; ra[buf][i][1] = q[1];
         }
-#pragma unroll
-        for (int j = 0; j < NV; ++j) { rb[buf][j][0] = bp[j][(size_t)kc * 128]; rb[buf][j][1] = bp[j][(size_t)kc * 128 + 64]; }
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int slot) {
         bf16x8 ah[2], al[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) split_frag(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
@@ -169,23 +172,30 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* 
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][j] = CFN_MFMA16(al[i], rb[buf][j][0], acc[i][j]);      // small terms first
-                acc[i][j] = CFN_MFMA16(ah[i], rb[buf][j][1], acc[i][j]);
-                acc[i][j] = CFN_MFMA16(ah[i], rb[buf][j][0], acc[i][j]);
+                acc[i][j] = CFN_MFMA16(al[i], rb[slot][j][0], acc[i][j]);      // small terms first
+                acc[i][j] = CFN_MFMA16(ah[i], rb[slot][j][1], acc[i][j]);
+                acc[i][j] = CFN_MFMA16(ah[i], rb[slot][j][0], acc[i][j]);
             }
     };
-    issue(0, 0);
-    int kc = 0;
-    for (; kc + 1 < KC; kc += 2) {
-        issue(1, kc + 1);
-        compute(0);
-        issue(0, (kc + 2 < KC) ? kc + 2 : KC - 1);
-        compute(1);
+    const int last = KC - 1;
+#pragma unroll
+    for (int q = 0; q < kPre16; ++q) issue_b(q, min(q, last));
+    issue_a(0, 0);
+    // unrolled by 6 (a multiple of the ring depth 2 or 3 and of the A ping-pong) so every register index is static
+    for (int kc = 0; kc < KC; kc += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = kc + u;
+            if (k < KC) {
+                issue_a((u + 1) & 1, min(k + 1, last));
+                compute(u & 1, u % kPre16);
+                issue_b(u % kPre16, min(k + kPre16, last));
+            }
+        }
     }
-    if (kc < KC) compute(0);
 }
 
-template <int NTW>
+template <int NTW, int PRE>
 __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const __bf16* __restrict__ wp16,
                                           const float* lds_a, int lda) {
     const int lane = lane_id_opaque();
@@ -202,17 +212,18 @@ __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, i
         if (nt >= (int)s.nt) nt = nt0;
         bp[j] = reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + (size_t)nt * KC * 128 + lane;
     }
-    if (nvalid == NTW) { mma_loop16<NTW, NTW>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 1 && nvalid == 1) { mma_loop16<NTW, 1>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 2 && nvalid == 2) { mma_loop16<NTW, (NTW > 2 ? 2 : 1)>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 3 && nvalid == 3) { mma_loop16<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+    if (nvalid == NTW) { mma_loop16<NTW, NTW, PRE>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 1 && nvalid == 1) { mma_loop16<NTW, 1, PRE>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 2 && nvalid == 2) { mma_loop16<NTW, (NTW > 2 ? 2 : 1), PRE>(acc, bp, a_ptr, lda, KC); return; }
+    if (NTW > 3 && nvalid == 3) { mma_loop16<NTW, (NTW > 3 ? 3 : 1), PRE>(acc, bp, a_ptr, lda, KC); return; }
 }
 
 // precision-dispatching wrapper used by the fused kernels
-template <int NTW, int PREC>
+// PRE: depth of the B-fragment ring of the bf16 loop (2 when two workgroups share a CU, 3 when a wave is alone on its SIMD)
+template <int NTW, int PREC, int PRE = 2>
 __device__ __forceinline__ void mma_any(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const float* __restrict__ wp,
                                         const __bf16* __restrict__ wp16, const float* lds_a, int lda) {
-    if (PREC == PREC_BF16X3) mma_seg16<NTW>(acc, s, nt0, nts, wp16, lds_a, lda);
+    if (PREC == PREC_BF16X3) mma_seg16<NTW, PRE>(acc, s, nt0, nts, wp16, lds_a, lda);
     else mma_seg<NTW>(acc, s, nt0, nts, wp, lds_a, lda);
 }
 

@@ -155,12 +155,12 @@ void fused_fwd_kernel(const FwdArgs A) {
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
                 acc_zero(acc);
-                mma_any<C::NTW, PREC>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
                     encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
                     __syncthreads();
-                    mma_any<C::NTW, PREC>(acc, T.skipseg, wave, kWaves, wp, wp16, act, LD);
+                    mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.skipseg, wave, kWaves, wp, wp16, act, LD);
                 }
                 __syncthreads();
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
@@ -174,8 +174,8 @@ void fused_fwd_kernel(const FwdArgs A) {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
                 acc_zero(accF); acc_zero(accA);
-                mma_any<1, PREC>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
-                mma_any<C::NTW, PREC>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 store_tiles<1, ACT_NONE, PREC>(accA, T.ha, wave, kWaves, wp, hs, HLD, 0,
                                          A.st_ha ? A.st_ha + p0 * HA : nullptr, HA, rows_valid);
@@ -187,7 +187,7 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][C::NTV];
                 acc_zero(acc);
-                mma_any<C::NTV, PREC>(acc, T.vf, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vf, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
                     const int row = idx >> 5, c = idx & 31;
@@ -198,7 +198,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
-                mma_any<C::NTV, PREC>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
                 store_tiles<C::NTV, ACT_RELU, PREC, TRAIN>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
@@ -209,7 +209,7 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][1];
                 acc_zero(acc);
-                mma_any<1, PREC>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 store_tiles<1, ACT_NONE, PREC>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
@@ -221,8 +221,8 @@ void fused_fwd_kernel(const FwdArgs A) {
                 f32x16 acc[2][1];
                 acc_zero(acc);
                 const bool is_rgb = wave < 3;
-                if (is_rgb) mma_any<1, PREC>(acc, T.fr, wave, kWaves, wp, wp16, act + W / 2, LD);
-                else        mma_any<1, PREC>(acc, T.fa, 0, kWaves, wp, wp16, hs, HLD);
+                if (is_rgb) mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.fr, wave, kWaves, wp, wp16, act + W / 2, LD);
+                else        mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.fa, 0, kWaves, wp, wp16, hs, HLD);
                 __syncthreads();
                 const SubL s = is_rgb ? T.fr : T.fa;
                 const int nt = is_rgb ? wave : 0;
