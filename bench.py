@@ -19,7 +19,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -36,8 +35,19 @@ def gemm_flops_per_point(W=256, ha=32, hr=64, ic=63, icv=27, F=4):
     return 2 * macs
 
 
+def fern_rays(rng, n, H=378, W=504, focal=407.5658):
+    """Fern-shaped synthetic rays: LLFF fern at factor 8, near-identity pose, n random pixels."""
+    c2w = np.eye(4, dtype=np.float32)[:3]
+    c2w[:, 3] = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    pix = rng.choice(H * W, size=n, replace=False)
+    j, i = np.divmod(pix, W)
+    dirs = np.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i, dtype=np.float64)], -1)
+    rays_d = (dirs[:, None, :] * c2w[:3, :3]).sum(-1).astype(np.float32)
+    rays_o = np.broadcast_to(c2w[:3, 3], rays_d.shape).astype(np.float32)
+    return torch.tensor(np.stack([rays_o, rays_d], 0)), (H, W, focal)
+
+
 def synth_batch(rank, n, device):
-    from util_hip import fern_rays
     rng = np.random.default_rng(1000 + rank)
     rays, (H, Wd, focal) = fern_rays(rng, n)
     target = torch.tensor(rng.uniform(0, 1, (n, 3)), dtype=torch.float32)
@@ -48,8 +58,7 @@ def cpu_baseline(mode, budget_s=30.0):
     """The CPU oracle (op-for-op PyTorch-CPU restatement of the reference, oracle/) timed on this box's
     host cores on a bounded sample of the same workload.  The thread count is swept (all usable
     cores is NOT the fastest for these GEMM sizes) and the best setting is reported with its count."""
-    from oracle import cfnerf_oracle as O
-    from util_hip import fern_rays
+    from oracle import cfnerf_oracle as O      # the ONLY use of oracle/ in this file: the checker timed as the CPU baseline
     n_rays = N_RAND                              # the full per-GPU workload of one step
     cfg = O.OracleCfg(netwidth=W, K_samples=K)
     p = O.make_params(cfg, 0)
@@ -121,8 +130,6 @@ def main():
 
     import cfnerf_amd
     from cfnerf_amd import _lib as L
-    from oracle import cfnerf_oracle as O       # only for the deterministic weight generator + cpu_baseline
-    from util_hip import build_model
     try:
         from cfnerf_amd import train as T
         have_train = T.backward_available()
@@ -132,8 +139,9 @@ def main():
     if mode == "train" and not have_train:
         raise SystemExit("train mode requested but the backward kernels are not built")
 
-    cfg = O.OracleCfg(netwidth=W, K_samples=K)
-    _, kw_train, kw_test, model, _, _ = build_model(cfg, 0, device=dev)
+    torch.manual_seed(0)                        # same random-init weights on every rank (nn.Linear-style init of the product)
+    kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=W, netdepth=D, K_samples=K, device=dev))
+    model = kw_train["network_fn"]
     net = model.module
     rays, target, (H, Wd, focal) = synth_batch(rank, N_RAND, dev)
     lib = L.lib()

@@ -645,6 +645,21 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
 
 
 # --------------------------------------------------------------------------------------------
+def default_args(**over):
+    """argparse.Namespace with the reference's defaults for every flag create_nerf() reads (config_parser, RUN:556-719;
+    ``use_viewdirs`` on, as every shipped config sets it).  Keyword arguments override."""
+    import argparse
+    a = argparse.Namespace(
+        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=0, netdepth=8, netwidth=256, K_samples=4,
+        h_alpha_size=32, h_rgb_size=64, z_size=4, n_flows=4, type_flows="triangular", n_hidden=128, netchunk_per_gpu=1024 * 64,
+        n_gpus=1, lrate=5e-4, lrate_decay=250, ft_path=None, basedir="./logs/", dataname="leaves", expname="cfnerf", no_reload=True,
+        index_step=-1, is_train=True, uniformsample=False, perturb=1.0, N_samples=128, white_bkgd=False, raw_noise_std=0.0,
+        dataset_type="llff", no_ndc=False, lindisp=False, beta1=0.0, device=torch.device("cuda"))
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
 def save_checkpoint(path, global_step, network_fn, optimizer=None, trainer=None):
     """The reference's checkpoint dict (RUN:1085-1100): ``global_step``, ``network_fn_state_dict`` with the
     DataParallel ``module.`` key prefix, ``optimizer_state_dict``.  Like the reference's loader (RUN:360, commented

@@ -18,7 +18,7 @@ DEV = "cuda"
 #  * trunk layers (pts_linears.*): a handful of ReLU masks flip between two fp32 implementations - units whose
 #    pre-activation lies below the fp32 noise of the 2^9-frequency positional encoding (measured: 4 rows of 6144,
 #    one unit each).  Each flip moves a summed gradient by ~1/P; the reference's OWN fp32-vs-fp64 gradients differ by
-#    1e-3 on these tensors (tools/grad_diag.py).  So the trunk check is a max-error bound plus a tight L2 bound.
+#    1e-3 on these tensors (tests/tools/grad_diag.py).  So the trunk check is a max-error bound plus a tight L2 bound.
 G_TIGHT, G_TRUNK_MAX, G_TRUNK_L2 = 2e-4, 6e-3, 3e-3
 
 

@@ -1,6 +1,6 @@
 """Development aid: throughput of the other BASELINE configs on one GPU (C3 train, C4 per-GPU shard, C5 eval)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cfnerf_amd

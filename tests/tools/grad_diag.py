@@ -1,6 +1,6 @@
 """Development aid: per-tensor gradient error of the HIP train step vs the fp32 and fp64 CPU oracle."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cfnerf_amd

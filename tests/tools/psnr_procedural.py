@@ -4,7 +4,7 @@ Analytic emissive-absorbing Gaussian blobs are rendered by dense quadrature (tor
 20 views on a sphere (17 train / 3 held out, like llffhold=8); the HIP path trains on them through the device ray
 pool + fused Trainer and is evaluated with the fused uncertainty render.  Prints one JSON line per precision mode."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cfnerf_amd

@@ -1,7 +1,7 @@
 """Quick timing of the fused forward (development aid; bench.py is the contract)."""
 import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import cfnerf_amd
 from oracle import cfnerf_oracle as O

@@ -1,6 +1,6 @@
 """Development aid: compare the stashed activations / backward intermediates with the oracle's autograd."""
 import sys, os, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import torch.nn.functional as F
