@@ -56,7 +56,12 @@ class Embedder:
         self.freq_bands = 2. ** torch.linspace(0., multires - 1, steps=multires)     # HLP:38
 
     def embed(self, inputs: torch.Tensor) -> torch.Tensor:
-        out = [inputs]
+        if inputs.is_cuda and inputs.shape[-1] == 3:                                  # the HIP kernel (cfnerf_embed)
+            x = _f32c(inputs.reshape(-1, 3))
+            out = torch.empty(x.shape[0], self.out_dim, device=x.device)
+            L.check(L.lib().cfnerf_embed(L.ptr(x), x.shape[0], self.multires, L.ptr(out), L.stream()), "cfnerf_embed")
+            return out.reshape(list(inputs.shape[:-1]) + [self.out_dim])
+        out = [inputs]                                                                # CPU tensors: plain torch, like the reference
         for f in self.freq_bands.tolist():                                            # HLP:42-45
             out.append(torch.sin(inputs * f))
             out.append(torch.cos(inputs * f))
@@ -560,22 +565,15 @@ def _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is
 
 def _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_rand, eps, is_train, lindisp, white_bkgd):
     """A caller-supplied network_query_fn: sample with torch, query through it, composite kernel."""
-    rays_o, rays_d, viewdirs = rays[:, 0:3], rays[:, 3:6], rays[:, 8:11]
-    near, far = rays[:, 6:7], rays[:, 7:8]
-    if not lindisp:
-        z_vals = near * (1. - t_vals) + far * t_vals
-    else:
-        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-    z_vals = z_vals.expand([rays.shape[0], t_vals.shape[0]])
-    if t_rand is not None:
-        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        z_vals = lower + (upper - lower) * t_rand
-    pts0 = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    rays_d, viewdirs = rays[:, 3:6], rays[:, 8:11]
+    N, S = rays.shape[0], t_vals.shape[0]
+    z_vals = torch.empty(N, S, device=rays.device)
+    pts0 = torch.empty(N, S, 3, device=rays.device)
+    L.check(L.lib().cfnerf_sample_points(L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.F_LINDISP if lindisp else 0, N, S, L.ptr(z_vals),
+                                         L.ptr(pts0), L.stream()), "cfnerf_sample_points")            # RUN:510-534
     model._next_eps = eps
     raw, loss_entropy = network_query_fn(pts0, viewdirs, network_fn, is_val=False, is_test=not is_train)
-    rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals.contiguous(), rays_d, 0., white_bkgd)
+    rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, 0., white_bkgd)
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'depth_map': depth_map}
     if is_train:
         ret.update(raw=raw, loss_entropy=loss_entropy, pts=pts0)

@@ -137,6 +137,23 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host, const fl
     return CFNERF_OK;
 }
 
+int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s) {
+    if (P < 0 || multires < 1 || multires > 16) return fail(CFNERF_E_INVALID, "bad P / multires (1..16)");
+    if (P == 0) return CFNERF_OK;
+    if (!x || !out) return fail(CFNERF_E_INVALID, "NULL argument");
+    HIPCHK(launch_embed(x, P, multires, out, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
+int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S, float* z_vals,
+                         float* pts, cfnerf_stream s) {
+    if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
+    if (N == 0) return CFNERF_OK;
+    if (!rays || !t_vals || !z_vals) return fail(CFNERF_E_INVALID, "NULL argument");
+    HIPCHK(launch_sample_points(rays, t_vals, t_rand, flags, N, S, z_vals, pts, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
 static int check_common(cfnerf_model* m, int K) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
     if (!m->flat) return fail(CFNERF_E_INVALID, "cfnerf_model_set_params has not been called");

@@ -483,6 +483,52 @@ __global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int u
 }
 
 // ---------------------------------------------------------------------------------------------
+// standalone positional encoding (HLP:21-69) and ray sampling (RUN:510-534): the unfused boundary functions
+__global__ void embed_kernel(const float* __restrict__ x, int64_t P, int nch, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * nch) return;
+    const int64_t p = idx / nch;
+    const int c = (int)(idx - p * nch);
+    out[idx] = enc_channel(x + p * 3, c);
+}
+
+__global__ void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ t_vals, const float* __restrict__ t_rand,
+                                     int flags, int64_t N, int S, float* __restrict__ z_out, float* __restrict__ pts) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * S) return;
+    const int64_t n = idx / S;
+    const int s = (int)(idx - n * S);
+    const float* r = rays + n * 11;
+    const float nearv = r[6], farv = r[7];
+    const bool lind = (flags & CFNERF_F_LINDISP) != 0;
+    const float zc = zlin_f(t_vals[s], nearv, farv, lind);
+    float zv = zc;
+    if (t_rand != nullptr) {
+        const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(t_vals[s + 1], nearv, farv, lind) + zc);
+        const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(t_vals[s - 1], nearv, farv, lind));
+        zv = lower + (upper - lower) * t_rand[idx];
+    }
+    z_out[idx] = zv;
+    if (pts != nullptr) {
+        pts[idx * 3 + 0] = r[0] + r[3] * zv; pts[idx * 3 + 1] = r[1] + r[4] * zv; pts[idx * 3 + 2] = r[2] + r[5] * zv;   // RUN:534
+    }
+}
+
+hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hipStream_t st) {
+    const int nch = 3 + 6 * multires;
+    const int64_t total = P * nch;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, P, nch, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S, float* z, float* pts,
+                                hipStream_t st) {
+    const int64_t total = N * S;
+    hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rays, t_vals, t_rand, flags, N, S, z, pts);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // EXTENSION: hierarchical resampling (semantics of nerf-pytorch's sample_pdf, the reference's upstream; the
 // reference itself has no second pass).  One wave per ray.
 constexpr int kPdfMax = 1024;            // S + N_importance

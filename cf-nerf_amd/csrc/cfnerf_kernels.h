@@ -45,6 +45,9 @@ hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int
                              int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out, hipStream_t st);
 hipError_t launch_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* w, const float* u,
                              int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st);
+hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hipStream_t st);
+hipError_t launch_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S, float* z, float* pts,
+                                hipStream_t st);
 hipError_t launch_pack(const float* flat, float* packed, void* packed16, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
 
 }  // namespace cfnerf

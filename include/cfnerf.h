@@ -92,6 +92,15 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] r
                       const float* rays_o, const float* rays_d, int64_t N, int64_t pixel0,
                       int ndc, float near_, float far_, float* rays /*[N,11]*/, cfnerf_stream s);
 
+/* replaces: Embedder.embed / get_embedder(multires) as a standalone call, HLP:21-69:
+ * x [P,3] -> out [P, 3 + 6*multires] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]        */
+int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s);
+
+/* replaces: the sampling lines of render_rays as a standalone call, RUN:510-534 (used by the unfused query path):
+ * rays [N,11], t_vals [S], t_rand [N,S] or NULL, LINDISP flag -> z_vals [N,S], pts [N,S,3]                      */
+int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S,
+                         float* z_vals, float* pts, cfnerf_stream s);
+
 /* ---- fused forward ---------------------------------------------------------------------------
  * replaces: render_rays() RUN:457-553 = sampling RUN:510-534, run_network RUN:67-85 with the
  * positional encoding HLP:21-69, NeRF_Flows.forward MOD:188-291 (TriangularSylvesterNeRF

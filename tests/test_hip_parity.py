@@ -312,3 +312,30 @@ def test_k_above_the_limit_and_bad_widths_are_rejected():
         cfnerf_amd.render_rays(torch.zeros(2, 11, device=DEV) + 0.5, **{k: v for k, v in kw.items() if k != "use_viewdirs"})
     with pytest.raises(RuntimeError, match="netwidth"):
         cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=96)))
+
+
+# ---------------------------------------------------------------- standalone boundary kernels
+def test_embedder_kernel_vs_reference_golden(golden):
+    g = golden("g8_encoder")
+    f10, d10 = cfnerf_amd.get_embedder(10, 0)
+    f4, d4 = cfnerf_amd.get_embedder(4, 0)
+    assert (d10, d4) == (int(g["d10"]), int(g["d4"]))
+    x = T(g["x"]).to(DEV)
+    close(f10(x), g["e10"], atol=2e-6, rtol=1e-5, what="embed multires 10")     # sin(512 x): one ulp of the argument = 3e-5 rad
+    close(f4(x), g["e4"], atol=1e-6, rtol=1e-6, what="embed multires 4")
+    assert f10(x.reshape(4, 4, 3)).shape == (4, 4, 63)
+
+
+def test_sample_points_kernel_vs_reference_golden(golden):
+    g = golden("g57_render_w64_ndc")
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    rays = T(g["rays"])
+    packed = O.pack_rays(H, W, focal, rays[0], rays[1], True, 0., 1.).to(DEV)
+    from cfnerf_amd import _lib as L
+    N, S = packed.shape[0], 128
+    z = torch.empty(N, S, device=DEV)
+    pts = torch.empty(N, S, 3, device=DEV)
+    tv = cfnerf_amd.t_vals_table(DEV)
+    tr = T(g["t_rand"]).to(DEV)
+    L.check(L.lib().cfnerf_sample_points(L.ptr(packed), L.ptr(tv), L.ptr(tr), 0, N, S, L.ptr(z), L.ptr(pts), L.stream()), "sample_points")
+    close(pts, g["pts"], atol=1e-6, rtol=1e-6, what="pts")
