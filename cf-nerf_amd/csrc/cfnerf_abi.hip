@@ -117,7 +117,9 @@ int cfnerf_model_destroy(cfnerf_model* m) {
 int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s) {
     if (!m || !flat_params) return fail(CFNERF_E_INVALID, "NULL argument");
     m->flat = flat_params;
-    HIPCHK(launch_pack(flat_params, m->d_packed, m->d_packed16, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, (hipStream_t)s));
+    // the split-bf16 copy is only refreshed while the opt-in mode is selected
+    HIPCHK(launch_pack(flat_params, m->d_packed, m->precision ? m->d_packed16 : nullptr, m->d_descs, (int)m->plan.descs.size(),
+                       m->plan.total_elems, (hipStream_t)s));
     return CFNERF_OK;
 }
 
@@ -253,7 +255,13 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
 int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
     if (mode != 0 && mode != 1) return fail(CFNERF_E_INVALID, "precision mode must be 0 (fp32 MFMA) or 1 (bf16x3 split MFMA)");
+    const bool need_pack16 = mode != 0 && m->precision == 0 && m->flat != nullptr;
     m->precision = mode;
+    if (need_pack16) {      // bring the bf16 copy up to date with the current parameters (rare call: fully synchronous)
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(launch_pack(m->flat, m->d_packed, m->d_packed16, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+    }
     return CFNERF_OK;
 }
 

@@ -43,6 +43,9 @@ struct DwTile {
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };
 
+// a parameter tensor's start offset and the number of split slots its gradient partials occupy
+struct RedSeg { uint32_t begin; int32_t nsplit; };
+
 // one workgroup of a weight-gradient launch: tile index, split slot and its point range
 struct DwBlock { int32_t tile, split, kslice, pad_; int64_t pb, pe; };
 
@@ -57,6 +60,7 @@ struct BwdPlan {
     DwTile *d_tiles = nullptr, *d_tiles_small = nullptr;
     DwBlock *d_blocks = nullptr, *d_blocks_small = nullptr;
     int n_blocks = 0, n_blocks_small = 0;
+    RedSeg* d_segs = nullptr; int n_segs = 0;
     const float* tiles_for = nullptr; int64_t tiles_P = 0;
     void release() {
         if (d_bias_maps) (void)hipFree(d_bias_maps);
@@ -73,6 +77,8 @@ struct BwdPlan {
         if (d_tiles_small) (void)hipFree(d_tiles_small);
         if (d_blocks) (void)hipFree(d_blocks);
         if (d_blocks_small) (void)hipFree(d_blocks_small);
+        if (d_segs) (void)hipFree(d_segs);
+        d_segs = nullptr; n_segs = 0;
         d_tiles = d_tiles_small = nullptr; d_blocks = d_blocks_small = nullptr;
         n_blocks = n_blocks_small = 0; tiles_for = nullptr; tiles_P = 0;
     }

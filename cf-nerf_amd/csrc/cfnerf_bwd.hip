@@ -678,12 +678,19 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
 
 // ================================================================================================
 // 5. reductions into grad_flat
-__global__ void reduce_weights_kernel(const float* __restrict__ partials, int nsplit, int64_t n_params, float* __restrict__ grad) {
+// grad[i] = sum over the split slots that the tensor containing i actually uses (segments sorted by offset)
+__global__ void reduce_weights_kernel(const float* __restrict__ partials, const RedSeg* __restrict__ segs, int n_segs, int64_t n_params,
+                                      float* __restrict__ grad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_params) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partials[(size_t)k * n_params + i];
-    grad[i] = s;
+    int lo = 0, hi = n_segs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)segs[mid].begin <= i) lo = mid; else hi = mid - 1; }
+    const int ns = segs[lo].nsplit;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < ns; k += 2) { s0 += partials[(size_t)k * n_params + i]; s1 += partials[(size_t)(k + 1) * n_params + i]; }
+    if (k < ns) s0 += partials[(size_t)k * n_params + i];
+    grad[i] = s0 + s1;
 }
 
 __global__ __launch_bounds__(1024)
@@ -976,6 +983,22 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         // split slots a tile does not write must read as zero in the reduction
         BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)kMaxSplit * n_params * sizeof(float), st));
         BHIP(hipStreamSynchronize(st));       // the vectors are host temporaries
+        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots)
+        {
+            std::vector<RedSeg> segs;
+            for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; segs.push_back(r); }
+            auto mark = [&](const std::vector<DwTile>& tv, int ns) {
+                for (const DwTile& t : tv)
+                    for (int q = 0; q < t.nseg; ++q)
+                        for (RedSeg& r : segs)
+                            if (r.begin == t.seg_dst[q]) r.nsplit = std::max(r.nsplit, ns);
+            };
+            mark(big, ns_big); mark(small, ns_small);
+            if (B.d_segs) (void)hipFree(B.d_segs);
+            BHIP(hipMalloc(&B.d_segs, segs.size() * sizeof(RedSeg)));
+            BHIP(hipMemcpyAsync(B.d_segs, segs.data(), segs.size() * sizeof(RedSeg), hipMemcpyHostToDevice, st));
+            B.n_segs = (int)segs.size();
+        }
         B.n_blocks = (int)bb.size(); B.n_blocks_small = (int)sb.size();
         B.tiles_for = q.h; B.tiles_P = P;
         static bool attr_set = false;
@@ -1026,7 +1049,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
                            B.d_partials, n_params, B.d_zeros);
         BHIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, kMaxSplit,
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, B.d_segs, B.n_segs,
                        n_params, grad_flat);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, B.d_dbp, grid_bd, B.nb,
