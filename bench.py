@@ -95,9 +95,15 @@ def cpu_baseline(mode, budget_s=30.0):
         tried.append(thr)
         if dt < best:
             best, best_thr = dt, thr
-    return {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
-            "sample": f"{n_rays} rays x {S} samples x K={K}, W={W}: one {mode} step of the PyTorch-CPU oracle per thread count, best at "
-                      f"{best_thr} threads (tried {tried}; {usable} usable cores; anomaly detection off)"}
+    out = {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
+           "sample": f"{n_rays} rays x {S} samples x K={K}, W={W}: one {mode} step of the PyTorch-CPU oracle per thread count, best at "
+                     f"{best_thr} threads (tried {tried}; {usable} usable cores; anomaly detection off)"}
+    if mode == "train" and time.perf_counter() - t_start < budget_s:
+        # the reference ships with torch.autograd.set_detect_anomaly(True) (HLP:2, MOD:5): one more step that way
+        torch.set_num_threads(best_thr)
+        with torch.autograd.set_detect_anomaly(True):
+            out["value_anomaly_on"] = n_rays / one()
+    return out
 
 
 def main():
