@@ -154,6 +154,46 @@ def _shape_of(key: str, numel: int, cfg: L.Cfg):
 
 
 # --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def reference_init(shapes, netdepth, K_samples=None):
+    """Initial values exactly as ``NeRF_Flows.__init__`` produces them under the same ``torch.manual_seed``
+    (MOD:38-67, 339-350).  Throw-away CPU ``nn.Linear``s are created in the reference's construction order, so torch's
+    own default init (U(+-1/sqrt(fan_in)) for weight and bias) consumes the CPU generator identically, and the fixed
+    latents are drawn at the same point of the stream (MOD:50-55: after ``views_linears``, before ``feature_linear``).
+
+    ``shapes``: key -> shape in state_dict order.  Returns ``(values, (sample_alpha, sample_rgb) | None)``; with
+    ``K_samples=None`` the latent draws are skipped (re-initialisation of an existing module)."""
+    vals = OrderedDict()
+
+    def lin(prefix):
+        out_f, in_f = shapes[prefix + ".weight"]
+        l = nn.Linear(in_f, out_f)
+        vals[prefix + ".weight"], vals[prefix + ".bias"] = l.weight.detach(), l.bias.detach()
+
+    for i in range(netdepth):
+        lin(f"pts_linears.{i}")                                            # MOD:38-39
+    lin("views_linears.0")                                                 # MOD:42
+    vals["alpha_mean"], vals["alpha_std"] = torch.zeros(1), torch.ones(1)  # MOD:44-45
+    vals["rgb_mean"], vals["rgb_std"] = torch.zeros(3), torch.ones(3)      # MOD:47-48
+    latents = None
+    if K_samples is not None:
+        # MOD:50-51: two `intepolation_*` latents come first.  They only feed NeRF_Flows.interpolation, which - like
+        # .sample - cannot run in the reference (both call the flows without the required is_test argument), so the
+        # draws are made for the RNG stream and dropped.
+        torch.empty([2, 1]).normal_()
+        torch.empty([2, 3]).normal_()
+        latents = (torch.empty([K_samples, 1]).normal_(), torch.empty([K_samples, 3]).normal_())     # MOD:54-55
+    for name in ("feature_linear", "alpha_linear", "alpha_std_linear", "h_alpha_linear", "h_rgb_linear"):
+        lin(name)                                                          # MOD:58-62
+    for flow in ("flows_rgb", "flows_alpha"):                              # MOD:66-67
+        for name in ("amor_d", "amor_diag1.0", "amor_diag2.0", "amor_b"):
+            lin(f"{flow}.{name}")                                          # MOD:339-350
+    missing = set(shapes) - set(vals)
+    if missing:
+        raise RuntimeError(f"reference_init: no rule for {sorted(missing)}")
+    return vals, latents
+
+
 class NeRF_Flows(nn.Module):
     """Drop-in for the reference's ``NeRF_Flows`` (MOD:13-291).
 
@@ -195,11 +235,8 @@ class NeRF_Flows(nn.Module):
         self.layout, n_params = param_layout(self.cfg)
         self.n_params = n_params
         self.flat = nn.Parameter(torch.zeros(n_params, dtype=torch.float32, device=dev))
-        self.reset_parameters()
-        # eval latents: plain attributes drawn at construction, NOT in state_dict (MOD:50-55)
         self.sample_size = args.K_samples
-        self.sample_alpha = torch.empty([self.sample_size, 1]).normal_()
-        self.sample_rgb = torch.empty([self.sample_size, 3]).normal_()
+        self._replay_reference_init(draw_latents=True)
         h = C.c_void_p()
         L.check(L.lib().cfnerf_model_create(C.byref(self.cfg), C.byref(h)), "cfnerf_model_create")
         self._h = h
@@ -211,21 +248,19 @@ class NeRF_Flows(nn.Module):
         return self.flat.data[off:off + n].view(_shape_of(key, n, self.cfg))
 
     @torch.no_grad()
-    def reset_parameters(self):
-        """nn.Linear default init (Kaiming-uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias);
-        base Gaussians mean 0 / std 1 (MOD:44-48)."""
-        for key in self.layout:
-            v = self.view(key)
-            if key in ("alpha_mean", "rgb_mean"):
-                v.zero_()
-            elif key in ("alpha_std", "rgb_std"):
-                v.fill_(1.0)
-            elif key.endswith(".weight"):
-                v.uniform_(-1.0 / math.sqrt(v.shape[1]), 1.0 / math.sqrt(v.shape[1]))
-            else:
-                w = self.view(key[:-len("bias")] + "weight")
-                v.uniform_(-1.0 / math.sqrt(w.shape[1]), 1.0 / math.sqrt(w.shape[1]))
+    def _replay_reference_init(self, draw_latents: bool):
+        shapes = OrderedDict((k, tuple(self.view(k).shape)) for k in self.layout)
+        vals, latents = reference_init(shapes, self.D, self.sample_size if draw_latents else None)
+        for k, v in vals.items():
+            self.view(k).copy_(v)
+        if draw_latents:
+            self.sample_alpha, self.sample_rgb = latents    # eval latents: plain attributes, NOT in state_dict
         self._dirty = True
+
+    def reset_parameters(self):
+        """Fresh nn.Linear default init (U(+-1/sqrt(fan_in)) for weight and bias), base Gaussians mean 0 / std 1; the
+        fixed eval latents are kept."""
+        self._replay_reference_init(draw_latents=False)
 
     def _buffers_ref(self):
         out = OrderedDict()

@@ -394,10 +394,12 @@ def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: Tensor, rays_d: 
     return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)     # HLP:374-375
 
 
-def pack_rays(H, W, focal, rays_o: Tensor, rays_d: Tensor, ndc: bool, near: float, far: float):
+def pack_rays(H, W, focal, rays_o: Tensor, rays_d: Tensor, ndc: bool, near: float, far: float, c2w_staticcam=None):
     """RUN:136-158: viewdirs from the world direction (before NDC), then NDC, then the [N,11] pack."""
-    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)            # RUN:143
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)            # RUN:143 (taken before the staticcam swap)
     viewdirs = viewdirs.reshape(-1, 3)
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, focal, c2w_staticcam)               # RUN:139-141
     if ndc:
         rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)          # RUN:149
     rays_o = rays_o.reshape(-1, 3)
@@ -408,14 +410,14 @@ def pack_rays(H, W, focal, rays_o: Tensor, rays_d: Tensor, ndc: bool, near: floa
 
 
 def render(p, H, W, focal, cfg: OracleCfg, eps_alpha, eps_rgb, is_train: bool, rays=None, c2w=None,
-           ndc=True, near=0., far=1., t_rand=None, lindisp=False, white_bkgd=False):
+           ndc=True, near=0., far=1., t_rand=None, lindisp=False, white_bkgd=False, c2w_staticcam=None):
     """RUN:103-170 restated; returns the render_rays dict reshaped to the ray batch shape."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, focal, c2w)                         # RUN:131
     else:
         rays_o, rays_d = rays                                               # RUN:134
     sh = rays_d.shape
-    packed = pack_rays(H, W, focal, rays_o, rays_d, ndc, near, far)
+    packed = pack_rays(H, W, focal, rays_o, rays_d, ndc, near, far, c2w_staticcam)
     ret = render_rays(p, packed, cfg, eps_alpha, eps_rgb, is_train, t_rand, lindisp, white_bkgd)
     out = {}
     for k, v in ret.items():

@@ -307,9 +307,16 @@ def main():
         rgbs_e, disp_e, depth_e, _ = R.render(6, 8, 7.0, chunk=8192, c2w=c2w, near=0., far=1., **kw_test)
         ro, rd = HLP.get_rays(6, 8, 7.0, c2w)
         no, nd = HLP.ndc_rays(6, 8, 7.0, 1., ro, rd)
+    # c2w_staticcam (RUN:139-141): view directions from c2w, ray geometry from the static camera
+    th2 = -0.2
+    c2w_static = torch.tensor([[np.cos(th2), 0, np.sin(th2), -0.05], [0, 1, 0, 0.1], [-np.sin(th2), 0, np.cos(th2), 0.2]],
+                              dtype=torch.float32)
+    with torch.no_grad():
+        rgbs_s, disp_s, depth_s, _ = R.render(6, 8, 7.0, chunk=8192, c2w=c2w, c2w_staticcam=c2w_static, near=0., far=1., **kw_test)
     out["g6_render_c2w"] = dict(seed=31, netwidth=64, K=4, H=6, W=8, focal=7.0, c2w=c2w, eps_alpha=ea, eps_rgb=er,
                                 rgb_map=rgbs_e, disp_map=disp_e, depth_map=depth_e, rays_o=ro, rays_d=rd,
-                                ndc_o=no, ndc_d=nd)
+                                ndc_o=no, ndc_d=nd, c2w_static=c2w_static, rgb_map_static=rgbs_s, disp_map_static=disp_s,
+                                depth_map_static=depth_s)
 
     # ---------------- G9: sparsification curves (HLP:382-438), the AUSE helper ----------------
     var_vec = torch.tensor(rng.uniform(0.0, 1.0, 1000) ** 2, dtype=torch.float32)
@@ -324,7 +331,29 @@ def main():
             g9[f"byvar_{ut}_{et}"] = b
     out["g9_sparsification"] = g9
 
+    # ---------------- G11: seeded construction (RUN:317-331, MOD:38-67): torch.manual_seed -> create_nerf ----------------
+    g11 = {}
+    for tag, wd, ks, depth in (("w64", 64, 3, 8), ("w256", 256, 4, 8), ("w128d6", 128, 2, 6)):
+        cfg = O.OracleCfg(netwidth=wd, K_samples=ks, netdepth=depth)
+        args = ref_args(cfg, tmp, K_samples=ks)
+        torch.manual_seed(1234)
+        kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+        net = kw_train["network_fn"].module
+        g11[f"{tag}.netwidth"], g11[f"{tag}.K"], g11[f"{tag}.netdepth"] = wd, ks, depth
+        g11[f"{tag}.sample_alpha"], g11[f"{tag}.sample_rgb"] = net.sample_alpha, net.sample_rgb
+        for k, v in net.state_dict().items():
+            if v.dtype != torch.float32 or "mask" in k:
+                continue
+            f = v.detach().reshape(-1)
+            g11[f"{tag}.head.{k}"] = f[:8].clone()                      # first values, exact
+            g11[f"{tag}.sum.{k}"] = f.double().sum()                    # float64 checksum of the whole tensor
+            g11[f"{tag}.sumsq.{k}"] = (f.double() ** 2).sum()
+    out["g11_seeded_init"] = g11
+
+    only = set(sys.argv[1:])                 # optional: regenerate only the named fixtures
     for name, d in out.items():
+        if only and name not in only:
+            continue
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **t2n(d))
         print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")

@@ -134,3 +134,28 @@ def test_host_mirror_rejects_cpu_tensors_and_dead_flags():
         cfnerf_amd.raw2outputs(torch.zeros(2, 4, 1, 4), torch.zeros(2, 4), torch.zeros(2, 3))
     with pytest.raises(ValueError, match="use_viewdirs"):
         cfnerf_amd.render(4, 4, 1.0, rays=(torch.zeros(1, 3), torch.zeros(1, 3)), use_viewdirs=False)
+
+
+@pytest.mark.parametrize("tag", ["w64", "w256", "w128d6"])
+def test_seeded_construction_replays_the_reference_rng_stream(golden, tag):
+    """torch.manual_seed(s); create_nerf(args) gives the reference's weights and eval latents bit for bit (G11:
+    generated by constructing the real reference under seed 1234).  Device-free host logic: api.reference_init."""
+    import torch
+    from cfnerf_amd import api
+    g = golden("g11_seeded_init")
+    W, K, D = int(g[f"{tag}.netwidth"]), int(g[f"{tag}.K"]), int(g[f"{tag}.netdepth"])
+    cfg = api._cfg_struct(D, W, 10, 4, 32, 64, 4)
+    layout, n_params = api.param_layout(cfg)
+    from collections import OrderedDict
+    shapes = OrderedDict((k, api._shape_of(k, n, cfg)) for k, (off, n) in layout.items())
+    torch.manual_seed(1234)
+    vals, (sa, sr) = api.reference_init(shapes, D, K)
+    assert np.array_equal(sa.numpy(), g[f"{tag}.sample_alpha"]) and np.array_equal(sr.numpy(), g[f"{tag}.sample_rgb"])
+    n_checked = 0
+    for k, v in vals.items():
+        f = v.reshape(-1)
+        assert np.array_equal(f[:8].numpy(), g[f"{tag}.head.{k}"]), k
+        assert float(f.double().sum()) == float(g[f"{tag}.sum.{k}"]), k
+        assert float((f.double() ** 2).sum()) == float(g[f"{tag}.sumsq.{k}"]), k
+        n_checked += f.numel()
+    assert n_checked == n_params

@@ -6,7 +6,7 @@ import torch
 
 import cfnerf_amd
 from oracle import cfnerf_oracle as O
-from util_hip import ATOL, ATOL_DISP, RTOL, build_model, close, fern_rays
+from util_hip import ATOL, ATOL_DISP, RTOL, build_model, close, fern_rays, make_args
 
 pytestmark = pytest.mark.gpu
 T = lambda a: torch.tensor(np.asarray(a))
@@ -134,6 +134,12 @@ def test_render_c2w_vs_reference_golden(golden):
     close(rgbs, g["rgb_map"], what="rgb_map")
     close(depth, g["depth_map"], what="depth_map")
     close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    with torch.no_grad():   # RUN:139-141
+        rgbs, disp, depth, _ = cfnerf_amd.render(H, W, focal, chunk=8192, c2w=T(g["c2w"]), c2w_staticcam=T(g["c2w_static"]),
+                                                 near=0., far=1., **kw_test)
+    close(rgbs, g["rgb_map_static"], what="rgb_map (staticcam)")
+    close(depth, g["depth_map_static"], what="depth_map (staticcam)")
+    close(disp, g["disp_map_static"], atol=ATOL_DISP, rtol=1e-3, what="disp_map (staticcam)")
 
 
 @pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True)])
@@ -339,3 +345,20 @@ def test_sample_points_kernel_vs_reference_golden(golden):
     tr = T(g["t_rand"]).to(DEV)
     L.check(L.lib().cfnerf_sample_points(L.ptr(packed), L.ptr(tv), L.ptr(tr), 0, N, S, L.ptr(z), L.ptr(pts), L.stream()), "sample_points")
     close(pts, g["pts"], atol=1e-6, rtol=1e-6, what="pts")
+
+
+def test_seeded_create_nerf_matches_reference_construction(golden):
+    """torch.manual_seed(1234); create_nerf(args) -> the reference's initial state_dict and eval latents (G11)."""
+    g = golden("g11_seeded_init")
+    cfg = O.OracleCfg(netwidth=256, K_samples=4)
+    torch.manual_seed(1234)
+    kw_train, _, _, _, _ = cfnerf_amd.create_nerf(make_args(cfg))
+    net = kw_train["network_fn"].module
+    assert np.array_equal(net.sample_alpha.numpy(), g["w256.sample_alpha"]) and np.array_equal(net.sample_rgb.numpy(), g["w256.sample_rgb"])
+    sd = net.state_dict()
+    for key in list(g):
+        if key.startswith("w256.head."):
+            k = key[len("w256.head."):]
+            f = sd[k].reshape(-1).cpu()
+            assert np.array_equal(f[:8].numpy(), g[key]), k
+            assert float(f.double().sum()) == float(g["w256.sum." + k]), k

@@ -181,6 +181,12 @@ def test_render_c2w(golden):
     close(e["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5)
     close(e["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5)
     close(e["disp_map"], g["disp_map"], atol=5e-5, rtol=5e-5)
+    # c2w_staticcam (RUN:139-141): view directions of c2w on the static camera's rays
+    e = O.render(p, H, W, focal, cfg, ea, er, False, c2w=T(g["c2w"]), near=0., far=1., c2w_staticcam=T(g["c2w_static"]))
+    close(e["rgb_map"], g["rgb_map_static"], atol=5e-6, rtol=5e-5)
+    close(e["depth_map"], g["depth_map_static"], atol=5e-6, rtol=5e-5)
+    close(e["disp_map"], g["disp_map_static"], atol=5e-5, rtol=5e-5)
+    assert (T(g["rgb_map_static"]) - T(g["rgb_map"])).abs().max() > 1e-4     # not degenerate: 10x the tolerance above
 
 
 def test_oracle_fp64_vs_fp32_drift(golden):
