@@ -273,7 +273,7 @@ def main():
                  ndc=int(not over.get("no_ndc", False)), lindisp=int(over.get("lindisp", False)),
                  white_bkgd=int(over.get("white_bkgd", False)), beta1=beta1,
                  rays=rays_t, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, target=target,
-                 rgb_map=rgbs, disp_map=disp, depth_map=depth, raw=extras["raw"], pts=extras["pts"],
+                 rgb_map=rgbs, disp_map=disp, depth_map=depth, raw_first4=extras["raw"][:4], pts=extras["pts"],
                  loss_entropy=loss_entropy, loss_entropy_numel=extras["loss_entropy"].numel(),
                  loss_nll=loss_nll, loss=loss, mse=mse, psnr=psnr.reshape(-1)[0],
                  rgb_map_eval=rgbs_e, disp_map_eval=disp_e, depth_map_eval=depth_e,
@@ -349,6 +349,19 @@ def main():
             g11[f"{tag}.sum.{k}"] = f.double().sum()                    # float64 checksum of the whole tensor
             g11[f"{tag}.sumsq.{k}"] = (f.double() ** 2).sum()
     out["g11_seeded_init"] = g11
+
+    # ---------------- G12: IMPLICIT randomness under torch.manual_seed (RUN:524 -> MOD:234 -> MOD:246) ----------------
+    # no patched call sites: the reference draws t_rand, eps_alpha, eps_rgb itself from the seeded CPU generator
+    rng12 = np.random.default_rng(112)          # own stream: adding this fixture does not move the others
+    cfg = O.OracleCfg(netwidth=64, K_samples=4)
+    args, kw_train, kw_test, model, p, _ = build_reference_model(R, cfg, 51, tmp, K_samples=4)
+    rays, (H, W, focal) = fern_rays(rng12, 24)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=torch.tensor(rays), near=0., far=1., **kw_train)
+    out["g12_seeded_draws"] = dict(seed=51, torch_seed=4321, netwidth=64, K=4, rays=rays, H=H, W=W, focal=focal,
+                                   rgb_map=rgbs, disp_map=disp, depth_map=depth, raw_first4=extras["raw"][:4],
+                                   loss_entropy=extras["loss_entropy"].reshape(-1)[0])
 
     only = set(sys.argv[1:])                 # optional: regenerate only the named fixtures
     for name, d in out.items():

@@ -362,3 +362,21 @@ def test_seeded_create_nerf_matches_reference_construction(golden):
             f = sd[k].reshape(-1).cpu()
             assert np.array_equal(f[:8].numpy(), g[key]), k
             assert float(f.double().sum()) == float(g["w256.sum." + k]), k
+
+
+def test_seeded_implicit_draws_match_reference(golden):
+    """G12: with no explicit t_rand / eps the host mirror draws them from the seeded CPU generator in the
+    reference's order (RUN:524 -> MOD:234 -> MOD:246): same torch.manual_seed, same render."""
+    g = golden("g12_seeded_draws")
+    cfg = cfg_from(g)
+    _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]))
+    rays = T(g["rays"]).to(DEV)
+    torch.manual_seed(int(g["torch_seed"]))
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(int(g["H"]), int(g["W"]), float(g["focal"]), chunk=8192, rays=rays,
+                                                      near=0., far=1., **kw_train)
+    close(rgbs, g["rgb_map"], what="rgb_map")
+    close(depth, g["depth_map"], what="depth_map")
+    close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    close(extras["raw"][:4], g["raw_first4"], what="raw")
+    close(extras["loss_entropy"].mean(), g["loss_entropy"], what="loss_entropy")

@@ -199,3 +199,23 @@ def test_oracle_fp64_vs_fp32_drift(golden):
                  rays=(rays[0].double(), rays[1].double()), t_rand=T(g["t_rand"]).double(), **kw)
     close(r["rgb_map"], g["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map fp64 vs ref fp32")
     close(r["depth_map"], g["depth_map"], atol=1e-5, rtol=1e-4, what="depth fp64 vs ref fp32")
+
+
+def test_seeded_implicit_draw_order(golden):
+    """G12: the reference run with NO patched RNG call sites under torch.manual_seed.  Drawing t_rand [N,S], then
+    eps_alpha [K,1], then eps_rgb [K,3] from the same seeded CPU generator (RUN:524 -> MOD:234 -> MOD:246) and
+    feeding them to the oracle reproduces its outputs."""
+    g = golden("g12_seeded_draws")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    N, K = rays.shape[1], cfg.K_samples
+    torch.manual_seed(int(g["torch_seed"]))
+    t_rand = torch.rand([N, 128])
+    ea = torch.empty([K, 1]).normal_()
+    er = torch.empty([K, 3]).normal_()
+    r = O.render(p, int(g["H"]), int(g["W"]), float(g["focal"]), cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=t_rand)
+    close(r["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5)
+    close(r["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5)
+    close(r["raw"][:4], g["raw_first4"], atol=5e-6, rtol=5e-5)
+    close(r["loss_entropy"], g["loss_entropy"], atol=5e-6, rtol=5e-5)
