@@ -31,6 +31,47 @@ extern "C" void cfnerf_set_error_(const char* msg) {      // used by the other t
     std::snprintf(g_err, sizeof g_err, "%s", msg);
 }
 
+// device-side part of cfnerf_model_create; on failure the caller destroys the partially built handle
+static int model_init_device(cfnerf_model* m) {
+    const cfnerf_cfg* cfg = &m->cfg;
+    HIPCHK(hipGetDevice(&m->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, m->device));
+    m->n_cu = prop.multiProcessorCount;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CFNERF_E_UNSUPPORTED, "device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
+    const size_t pbytes = (size_t)m->plan.tab.packed_floats * sizeof(float);
+    HIPCHK(hipMalloc(&m->d_packed, pbytes));
+    HIPCHK(hipMemset(m->d_packed, 0, pbytes));
+    HIPCHK(hipMalloc(&m->d_packed16, (size_t)m->plan.tab.packed16_elems * 2));
+    HIPCHK(hipMemset(m->d_packed16, 0, (size_t)m->plan.tab.packed16_elems * 2));
+    HIPCHK(hipMalloc(&m->d_tab, sizeof(NetTab)));
+    HIPCHK(hipMemcpy(m->d_tab, &m->plan.tab, sizeof(NetTab), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
+    HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
+    HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
+    HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
+    for (int i = 0; i < kNumTimers; ++i) {
+        HIPCHK(hipEventCreate(&m->ev0[i]));
+        HIPCHK(hipEventCreate(&m->ev1[i]));
+    }
+    m->ws_bytes = pbytes + sizeof(NetTab);
+    return CFNERF_OK;
+}
+
+// a handle lives on the device that was current when it was created (one handle per device, one process per GPU)
+static int check_device(const cfnerf_model* m) {
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev != m->device)
+        return fail(CFNERF_E_INVALID, "model lives on device %d but the current device is %d (hipSetDevice / torch.cuda.set_device first)",
+                    m->device, dev);
+    return CFNERF_OK;
+}
+
+extern "C" int cfnerf_model_destroy(cfnerf_model* m);
+
 extern "C" {
 
 int cfnerf_version(void) { return 100; }
@@ -72,32 +113,11 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
     m->cfg = *cfg;
     m->layout = build_layout(*cfg);
     m->plan = build_pack_plan(*cfg, m->layout);
-    HIPCHK(hipGetDevice(&m->device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, m->device));
-    m->n_cu = prop.multiProcessorCount;
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        std::string arch = prop.gcnArchName;
-        delete m;
-        return fail(CFNERF_E_UNSUPPORTED, "device is %s; this library is built for gfx950 (MI355X) only", arch.c_str());
+    const int rc = model_init_device(m);
+    if (rc != CFNERF_OK) {                 // g_err already says why; release whatever was allocated
+        cfnerf_model_destroy(m);
+        return rc;
     }
-    const size_t pbytes = (size_t)m->plan.tab.packed_floats * sizeof(float);
-    HIPCHK(hipMalloc(&m->d_packed, pbytes));
-    HIPCHK(hipMemset(m->d_packed, 0, pbytes));
-    HIPCHK(hipMalloc(&m->d_packed16, (size_t)m->plan.tab.packed16_elems * 2));
-    HIPCHK(hipMemset(m->d_packed16, 0, (size_t)m->plan.tab.packed16_elems * 2));
-    HIPCHK(hipMalloc(&m->d_tab, sizeof(NetTab)));
-    HIPCHK(hipMemcpy(m->d_tab, &m->plan.tab, sizeof(NetTab), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
-    HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
-    m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
-    HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
-    HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
-    for (int i = 0; i < kNumTimers; ++i) {
-        HIPCHK(hipEventCreate(&m->ev0[i]));
-        HIPCHK(hipEventCreate(&m->ev1[i]));
-    }
-    m->ws_bytes = pbytes + sizeof(NetTab);
     *out = m;
     return CFNERF_OK;
 }
@@ -109,13 +129,14 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     hipFree(m->d_eps);
     m->stash.release();
     m->bwd.release();
-    for (int i = 0; i < kNumTimers; ++i) { hipEventDestroy(m->ev0[i]); hipEventDestroy(m->ev1[i]); }
+    for (int i = 0; i < kNumTimers; ++i) { if (m->ev0[i]) hipEventDestroy(m->ev0[i]); if (m->ev1[i]) hipEventDestroy(m->ev1[i]); }
     delete m;
     return CFNERF_OK;
 }
 
 int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s) {
     if (!m || !flat_params) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (int rc = check_device(m)) return rc;
     m->flat = flat_params;
     // the split-bf16 copy is only refreshed while the opt-in mode is selected
     HIPCHK(launch_pack(flat_params, m->d_packed, m->precision ? m->d_packed16 : nullptr, m->d_descs, (int)m->plan.descs.size(),
@@ -159,6 +180,7 @@ int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_
 static int check_common(cfnerf_model* m, int K) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
     if (!m->flat) return fail(CFNERF_E_INVALID, "cfnerf_model_set_params has not been called");
+    if (int rc = check_device(m)) return rc;
     if (K < 1 || K > kMaxK) return fail(CFNERF_E_UNSUPPORTED, "K_samples must be in [1,%d], got %d", kMaxK, K);
     return CFNERF_OK;
 }

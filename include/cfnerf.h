@@ -16,6 +16,11 @@
  *     nothing synchronises the host except cfnerf_model_create/destroy and workspace growth;
  *   - return value: 0 = OK, negative = cfnerf_status; cfnerf_last_error() gives a thread-local
  *     message.  No C++ exception crosses the ABI;
+ *   - a handle lives on the device that was current at cfnerf_model_create (one handle per device, one
+ *     process per GPU); calls made with another device current are rejected.  Calls that do not take a
+ *     handle are stateless and re-entrant.  Calls on ONE handle share its workspaces (entropy partials,
+ *     stash, split-K partials): issue them from one host thread at a time and on one stream at a time
+ *     (or order the streams with events); different handles are independent;
  *   - all arithmetic is fp32 (exact-fp32 MFMA v_mfma_f32_32x32x2_f32 for the dense layers).
  */
 #ifndef CFNERF_H
