@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcfnerf_hip.so")
+# CFNERF_LIB: development aid for same-box A/B runs of two builds of the SAME library (never a fallback)
+LIB_PATH = os.environ.get("CFNERF_LIB") or os.path.join(HERE, "libcfnerf_hip.so")
 
 F_TRAIN, F_LINDISP, F_WHITE_BKGD, F_STASH = 1, 2, 4, 8
 

@@ -41,6 +41,12 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
 }
 
 // 16*NV MFMAs of one k-chunk (8 k values): a0/a1 = A fragments of the two row tiles, b[j] = B fragments
+#ifndef CFN_MMA_PRIO
+#define CFN_MMA_PRIO 0
+#endif
+#ifndef CFN_EPI_PRIO
+#define CFN_EPI_PRIO 2
+#endif
 template <int NTW, int NV>
 __device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NTW], const f32x4 a0, const f32x4 a1, const f32x4 (&b)[NTW]) {
 #pragma unroll
@@ -59,6 +65,7 @@ template <int NTW, int NV>
 __device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* const (&bp)[NTW], const float* a_ptr,
                                          int lda, int KC) {
     f32x4 bA[NTW], bB[NTW], a0A, a1A, a0B, a1B;
+    __builtin_amdgcn_s_setprio(CFN_MMA_PRIO);
 #pragma unroll
     for (int j = 0; j < NV; ++j) bA[j] = bp[j][0];
     a0A = *reinterpret_cast<const f32x4*>(a_ptr);
@@ -78,6 +85,7 @@ __device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* con
         mma_block<NTW, NV>(acc, a0B, a1B, bB);
     }
     if (kc < KC) mma_block<NTW, NV>(acc, a0A, a1A, bA);       // odd KC tail (operands already loaded)
+    __builtin_amdgcn_s_setprio(CFN_EPI_PRIO);
 }
 
 // acc[i][j] += A[rows i*32..+31][0..8*kc) * B(tile nt0 + j*nts)       (one GEMM segment)
@@ -178,6 +186,7 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* 
             }
     };
     const int last = KC - 1;
+    __builtin_amdgcn_s_setprio(CFN_MMA_PRIO);
 #pragma unroll
     for (int q = 0; q < kPre16; ++q) issue_b(q, min(q, last));
     issue_a(0, 0);
@@ -193,6 +202,7 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* 
             }
         }
     }
+    __builtin_amdgcn_s_setprio(CFN_EPI_PRIO);
 }
 
 template <int NTW, int PRE>
