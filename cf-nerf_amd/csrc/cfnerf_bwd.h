@@ -39,6 +39,7 @@ struct DwTile {
     int32_t nseg, seg_row[4];                             // destination row segments (concatenated flow heads)
     uint32_t seg_dst[4];
     int32_t dst_ld, dst_col;
+    int32_t gk, wk;                                       // small kernel: waves along k, k-tiles per wave (GN = 8 / gk)
 };
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };

@@ -446,7 +446,6 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 //      through double-buffered LDS (32 points per stage) with register prefetch, so every dY / X element is
 //      read from HBM exactly once and the loads of stage s+1 fly under the 128 MFMAs per wave of stage s.
 constexpr int kDwRows = 32;                   // points per LDS stage
-constexpr int kDwSmallGroup = 4;              // dw_small_kernel: point-pairs per register group (2 groups in flight)
 constexpr int kDwThreads = 512;
 template <int PREC>
 __global__ __launch_bounds__(kDwThreads, 2)
@@ -582,97 +581,151 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
 }
 
-// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads): a block computes ONE 128 (n) x 64 (k)
-//      tile of one split; its 4 waves take a quarter of the block's points each (operands straight from global
-//      memory with a deep register pipeline) and tree-reduce their accumulators through LDS.  Only k-slices that
-//      exist are launched; the 4x intra-block split puts ~2 waves on every SIMD to hide the HBM latency.
-constexpr int kDwSmallWaves = 4;
-__global__ __launch_bounds__(64 * kDwSmallWaves, 2)
+// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  Same scheme as 4a at a finer grain:
+//      the 8 waves of a workgroup each own ONE 32 x 32 (or 32 x 64) output tile and are arranged GN x GK over the
+//      job (8 x 1 for a 256 x 63 encoding block, 1 x 8 for a 32 x 256 head, 2 x 4 for 64 x 128 ...), so only tiles
+//      that hold real rows / columns run MFMAs; operands are staged through double-buffered LDS (32 points per
+//      stage, full-row coalesced loads, every dY / X element read from HBM once per tile) with register prefetch.
+constexpr int kDsThreads = 512;
+constexpr int kDsSlots = 5;                   // 16-B loader chunks per thread and stage (32 rows x <= 320 columns)
+constexpr int kDsMaxCols = 288;               // staged columns per row: 32 * GN (dY) + 32 * GK * WK (X); 2 x 72 KB per CU
+__global__ __launch_bounds__(kDsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
                      const float* __restrict__ zeros) {
-    __shared__ float red[2][8][16][64];                    // two accumulator sets of 128 regs x 64 lanes (64 KB)
-    const int lane = lane_id_opaque(), wave = wave_id();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
-    const int kw0 = t.k0 + 64 * blk.kslice;
-    // this wave's quarter of the block's point range (multiples of the pipeline step)
-    const int64_t span = blk.pe - blk.pb;
-    int64_t q4 = (span + kDwSmallWaves - 1) / kDwSmallWaves;
-    q4 = (q4 + 4 * kDwSmallGroup - 1) / (4 * kDwSmallGroup) * (4 * kDwSmallGroup);
-    const int64_t pb = min(blk.pe, blk.pb + wave * q4), pe = min(blk.pe, pb + q4);
-    const int i = lane & 31, kk = lane >> 5;
-    const int ncol = t.n0 + 4 * i, kcol = kw0 + 2 * i;
-    const bool n_ok = ncol + 4 <= t.Npad;          // the 16-B vector stays inside the readable part of the dY row
-    const bool k_ok = kcol + 2 <= t.Kpad;
-    gcf_ptr yq = (gcf_ptr)t.dY + ncol;
-    gcf_ptr xq = (gcf_ptr)t.X + kcol;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
+    const int GK = t.gk, WK = t.wk, GN = 8 / GK;
+    const int a_ld = 32 * GN, b_ld = 32 * GK * WK;            // floats per staged row
+    float* As = smem;                                         // [2][32][a_ld]
+    float* Bs = smem + 2 * kDwRows * a_ld;                    // [2][32][b_ld]
+    const int64_t pb = blk.pb, pe = blk.pe;
     gcf_ptr zp = (gcf_ptr)zeros;
-    // unconditional loads; invalid rows / columns read a zero page (address select, nothing consumes the data early)
-    auto load = [&](int64_t p, f32x4& av, f32x2& bv) {
-        const int64_t pr = p + kk;
-        gcf_ptr pa = (pr < pe && n_ok) ? yq + pr * t.ldY : zp;
-        gcf_ptr pb_ = (pr < pe && k_ok) ? xq + pr * t.ldX : zp;
-        av = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
-        bv = *reinterpret_cast<const f32x2 __attribute__((address_space(1)))*>(pb_);
-    };
-    // two register groups of 8 point-pairs each: the loads of group g+1 (16 vectors per lane) are in flight
-    // under the 64 MFMAs (~4k cycles) of group g - operands come straight from HBM, latency ~2 us
-    constexpr int G = kDwSmallGroup;             // point-pairs per register group
-    f32x4 ga[G], ha[G]; f32x2 gb[G], hb[G];
-    int64_t p = pb;
+    // loader: a slot is one 16-B chunk per thread.  The first na slots carry dY rows, the next nb slots X rows
+    // (na + nb <= 5); within an operand a slot covers 512 / (chunks per row) consecutive rows, so the per-thread state
+    // is one (row, column) pair per operand and everything that differs between slots is workgroup-uniform.
+    const int ca = a_ld >> 2, cb = b_ld >> 2;                 // chunks per row: 8, 16, 32 or 64
+    const int lca = __builtin_ctz(ca), lcb = __builtin_ctz(cb);
+    const int rpa = kDsThreads >> lca, rpb = kDsThreads >> lcb;           // rows per slot
+    const int na = (kDwRows + rpa - 1) / rpa, nb = (kDwRows + rpb - 1) / rpb;
+    const int ra0 = tid >> lca, cola = 4 * (tid & (ca - 1));
+    const int rb0 = tid >> lcb, colb = 4 * (tid & (cb - 1));
+    const bool a_ok = t.n0 + cola + 4 <= t.Npad, b_ok = t.k0 + colb + 4 <= t.Kpad;   // the vector stays inside the readable row
+    const int a_off0 = ra0 * t.ldY + t.n0 + cola, b_off0 = rb0 * t.ldX + t.k0 + colb;
+    const int a_dst0 = ra0 * a_ld + cola, b_dst0 = rb0 * b_ld + colb;
+    f32x4 rg[kDsSlots];
+    // per-slot source pointers are kept across stages (advanced by a uniform stride), so a stage costs a compare, an
+    // address select and a 64-bit add per slot; rows or columns that do not exist read the zero page (the select is
+    // on the ADDRESS: nothing consumes a load early).  Everything that differs between slots is workgroup-uniform.
+    gcf_ptr src[kDsSlots];
+    bool sok[kDsSlots];
 #pragma unroll
-    for (int q = 0; q < G; ++q) load(p + 2 * q, ga[q], gb[q]);
-    for (; p < pe; p += 4 * G) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) load(p + 2 * G + 2 * q, ha[q], hb[q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(ga[q][tn], gb[q][0], acc[tn][0]); acc[tn][1] = CFN_MFMA(ga[q][tn], gb[q][1], acc[tn][1]); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < G; ++q) load(p + 4 * G + 2 * q, ga[q], gb[q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) { acc[tn][0] = CFN_MFMA(ha[q][tn], hb[q][0], acc[tn][0]); acc[tn][1] = CFN_MFMA(ha[q][tn], hb[q][1], acc[tn][1]); }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < kDsSlots; ++q) {
+        const bool is_a = q < na;
+        const int j = is_a ? q : q - na;
+        const int row = (is_a ? ra0 : rb0) + j * (is_a ? rpa : rpb);
+        sok[q] = (is_a ? a_ok : b_ok) && (j < (is_a ? na : nb)) && row < kDwRows;
+        src[q] = (is_a ? (gcf_ptr)t.dY + pb * t.ldY : (gcf_ptr)t.X + pb * t.ldX) + ((is_a ? a_off0 : b_off0) + j * (is_a ? rpa * t.ldY : rpb * t.ldX));
     }
-    // tree reduction of the 4 waves' accumulators through LDS: (2,3) -> (0,1), then 1 -> 0
-    auto put = [&](int slot) {
+    auto gload = [&](int rows_left) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[slot][a * 2 + b][r][lane] = acc[a][b][r];
+        for (int q = 0; q < kDsSlots; ++q) {
+            const bool is_a = q < na;
+            const int row = (is_a ? ra0 : rb0) + (is_a ? q * rpa : (q - na) * rpb);
+            gcf_ptr pa = (sok[q] && row < rows_left) ? src[q] : zp;
+            rg[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
+            src[q] += kDwRows * (is_a ? t.ldY : t.ldX);
+        }
     };
-    auto add = [&](int slot) {
+    auto sstore = [&](int buf) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] += red[slot][a * 2 + b][r][lane];
+        for (int q = 0; q < kDsSlots; ++q) {
+            const bool is_a = q < na;
+            const int j = is_a ? q : q - na;
+            const int row = (is_a ? ra0 : rb0) + j * (is_a ? rpa : rpb);
+            const bool ok = (j < (is_a ? na : nb)) && row < kDwRows;
+            float* dst = is_a ? As + buf * kDwRows * a_ld + a_dst0 + j * rpa * a_ld : Bs + buf * kDwRows * b_ld + b_dst0 + j * rpb * b_ld;
+            if (ok) *reinterpret_cast<f32x4*>(dst) = rg[q];
+        }
     };
-    if (wave >= 2) put(wave - 2);
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const int gn = wave / GK, gk = wave - gn * GK;
+    const int n_base = t.n0 + 32 * gn, k_base = t.k0 + 32 * WK * gk;
+    const bool active = n_base < t.N && k_base < t.K;         // wave-uniform
+    const int i = lane & 31, kk = lane >> 5;
+    const float* a_rd = As + kk * a_ld + 32 * gn + i;
+    const float* b_rd = Bs + kk * b_ld + 32 * WK * gk + WK * i;
+    // one stage = 16 point-pairs: the operands of 8 point-pairs are fetched from LDS into registers as a batch, so the
+    // ds_reads pipeline instead of each MFMA waiting on its own read
+    auto compute = [&](int buf) {
+        if (!active) return;
+        const float* ar = a_rd + buf * kDwRows * a_ld;
+        const float* br = b_rd + buf * kDwRows * b_ld;
+        if (WK == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float av[8]; f32x2 bv[8];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    av[pp] = ar[(h * 8 + pp) * 2 * a_ld];
+                    bv[pp] = *reinterpret_cast<const f32x2*>(br + (h * 8 + pp) * 2 * b_ld);
+                }
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    acc[0] = CFN_MFMA(av[pp], bv[pp][0], acc[0]);
+                    acc[1] = CFN_MFMA(av[pp], bv[pp][1], acc[1]);
+                }
+            }
+        } else {
+            float av[16], bv[16];
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) { av[pp] = ar[pp * 2 * a_ld]; bv[pp] = br[pp * 2 * b_ld]; }
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) acc[pp & 1] = CFN_MFMA(av[pp], bv[pp], acc[pp & 1]);   // two chains, summed at the end
+        }
+    };
+
+    int rows_left = (int)(pe - pb);                  // a split's point range is far below 2^31
+    gload(rows_left);
+    sstore(0);
     __syncthreads();
-    if (wave < 2) add(wave);
-    __syncthreads();
-    if (wave == 1) put(0);
-    __syncthreads();
-    if (wave == 0) {
-        add(0);
-        dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0, kw0, lane);
+    int buf = 0;
+    for (; rows_left > 0; rows_left -= kDwRows) {
+        const bool more = rows_left > kDwRows;
+        if (more) gload(rows_left - kDwRows);
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (!active) return;
+    if (WK == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
+    }
+    gf_ptr out = (gf_ptr)(partials + (size_t)blk.split * n_params);
+    for (int tk = 0; tk < WK; ++tk) {
+        const int k = k_base + WK * (lane & 31) + tk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n_base + frag_row(r, lane);
+            if (n < t.N && k < t.K) {
+                int sg = 0;
+                if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
+                if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
+                if (t.nseg > 3 && n >= t.seg_row[3]) sg = 3;
+                const uint32_t dst = sg == 0 ? t.seg_dst[0] : sg == 1 ? t.seg_dst[1] : sg == 2 ? t.seg_dst[2] : t.seg_dst[3];
+                const int row0 = sg == 0 ? t.seg_row[0] : sg == 1 ? t.seg_row[1] : sg == 2 ? t.seg_row[2] : t.seg_row[3];
+                out[(size_t)dst + (size_t)(n - row0) * t.dst_ld + t.dst_col + k] = tk == 0 ? acc[0][r] : acc[1][r];
+            }
+        }
     }
 }
 
@@ -686,11 +739,20 @@ __global__ void reduce_weights_kernel(const float* __restrict__ partials, const 
     int lo = 0, hi = n_segs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)segs[mid].begin <= i) lo = mid; else hi = mid - 1; }
     const int ns = segs[lo].nsplit;
-    float s0 = 0.f, s1 = 0.f;
+    // 8 independent loads per trip (the slots of one element are n_params apart: latency-bound otherwise); fixed
+    // summation order, so the result is deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* q = partials + i;
     int k = 0;
-    for (; k + 1 < ns; k += 2) { s0 += partials[(size_t)k * n_params + i]; s1 += partials[(size_t)(k + 1) * n_params + i]; }
-    if (k < ns) s0 += partials[(size_t)k * n_params + i];
-    grad[i] = s0 + s1;
+    for (; k + 7 < ns; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(k + u) * n_params];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; k < ns; ++k) s0 += q[(size_t)k * n_params];
+    grad[i] = (s0 + s1) + (s2 + s3);
 }
 
 __global__ __launch_bounds__(1024)
@@ -843,15 +905,24 @@ static int ensure_bwd_plan(cfnerf_model* m) {
     return 0;
 }
 
-// one weight-gradient job -> tiles: 256 x 256 ("big": LDS-staged kernel) when the job is at least 128 x 128,
-// else 128 x 256 ("small": direct-load kernel)
+// one weight-gradient job -> tiles: 256 x 256 ("big" kernel) when the job is at least 128 x 128; else ("small" kernel)
+// tiles of (32 GN) x (32 GK WK), GN GK = 8 waves, with the wave arrangement picked from the job's shape
 static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const float* dY, int ldY, int Nread, int N, const float* X,
                     int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
     const bool is_big = N >= 128 && Kvalid >= 128;
-    const int tn = is_big ? 256 : 128;
+    int gk = 0, wk = 0;
+    if (!is_big) {
+        const int kcols = std::min(Kvalid, 256);
+        if (kcols <= 32) { gk = 1; wk = 1; }
+        else if (kcols <= 64) { gk = 2; wk = 1; }
+        else if (kcols <= 128) { gk = 4; wk = 1; }
+        else { gk = 8; wk = 1; }
+    }
+    const int tn = is_big ? 256 : 32 * (8 / gk), tk = is_big ? 256 : 32 * gk * wk;
     for (int n0 = 0; n0 < N; n0 += tn)
-        for (int k0 = 0; k0 < Kvalid; k0 += 256) {
+        for (int k0 = 0; k0 < Kvalid; k0 += tk) {
             DwTile t{};
+            t.gk = gk; t.wk = wk;
             t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
             t.nseg = nseg;
             for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
@@ -904,15 +975,15 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
 
     // ---- workspace sizes that depend on the batch
     const int n_wg = m->n_cu * ((W <= 256) ? 2 : 1);
-    const int kMaxSplit = 64;
+    const int kMaxSplit = 64, kSlots = 128;      // split slots: big tiles use <= kMaxSplit, small jobs up to kSlots
     if (B.dbp_wg < n_wg || !B.d_dbp) {
         if (B.d_dbp) hipFree(B.d_dbp);
         BHIP(hipMalloc(&B.d_dbp, (size_t)n_wg * B.nb * sizeof(float)));
         B.dbp_wg = n_wg;
     }
     if (!B.d_partials) {
-        BHIP(hipMalloc(&B.d_partials, (size_t)kMaxSplit * n_params * sizeof(float)));
-        B.partials_split = kMaxSplit;
+        BHIP(hipMalloc(&B.d_partials, (size_t)kSlots * n_params * sizeof(float)));
+        B.partials_split = kSlots;
     }
     if (!B.d_zeros) {
         BHIP(hipMalloc(&B.d_zeros, 256));
@@ -966,11 +1037,11 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, big.size())));
         ns_big = std::min(ns_big, kMaxSplit);
         while (ns_big > 1 && P / ns_big < 512) --ns_big;
-        int ns_small = kMaxSplit;
+        int ns_small = kSlots;
         while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
         std::vector<DwBlock> bb, sb;
         make_blocks(bb, big, ns_big, P, kDwRows, false);
-        make_blocks(sb, small, ns_small, P, 4 * kDwSmallGroup, true);
+        make_blocks(sb, small, ns_small, P, kDwRows, false);
         B.release_tiles();
         BHIP(hipMalloc(&B.d_tiles, std::max<size_t>(1, big.size()) * sizeof(DwTile)));
         BHIP(hipMalloc(&B.d_tiles_small, std::max<size_t>(1, small.size()) * sizeof(DwTile)));
@@ -981,7 +1052,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         BHIP(hipMemcpyAsync(B.d_blocks, bb.data(), bb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
         BHIP(hipMemcpyAsync(B.d_blocks_small, sb.data(), sb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
         // split slots a tile does not write must read as zero in the reduction
-        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)kMaxSplit * n_params * sizeof(float), st));
+        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)kSlots * n_params * sizeof(float), st));
         BHIP(hipStreamSynchronize(st));       // the vectors are host temporaries
         // per-tensor split counts for the reduction (biases / dead tensors: 0 slots)
         {
@@ -1007,6 +1078,8 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
                                      (int)(4 * kDwRows * 256 * sizeof(float))));
             BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(4 * kDwRows * 256 * sizeof(float))));
+            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(2 * kDwRows * kDsMaxCols * sizeof(float))));
             attr_set = true;
         }
     }
@@ -1045,8 +1118,8 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
         BHIP(hipGetLastError());
     }
     if (B.n_blocks_small > 0) {
-        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(64 * kDwSmallWaves), 0, st, B.d_tiles_small, B.d_blocks_small,
-                           B.d_partials, n_params, B.d_zeros);
+        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(kDsThreads), 2 * kDwRows * kDsMaxCols * sizeof(float), st,
+                           B.d_tiles_small, B.d_blocks_small, B.d_partials, n_params, B.d_zeros);
         BHIP(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, B.d_segs, B.n_segs,
