@@ -931,6 +931,50 @@ static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
         }
 }
 
+// every weight-gradient job of the network (dW[n][k] = sum_p dY[p][n] X[p][k]) as big / small tiles.  `q` supplies
+// the operand base pointers (geometry only depends on the configuration: the CPU test of the plan passes fakes).
+static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash& q, int64_t P, std::vector<DwTile>& big,
+                          std::vector<DwTile>& small) {
+    const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
+    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    char key[64];
+    const int one_row[1] = {0};
+    for (int l = 0; l < D; ++l) {
+        std::snprintf(key, sizeof key, "pts_linears.%d.weight", l);
+        const uint32_t dst[1] = {(uint32_t)L.off(key)};
+        const float* dY = q.g_h + (size_t)l * P * W;
+        if (l == 0) {
+            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
+        } else if (l - 1 == skip) {
+            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
+            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
+        } else {
+            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
+        }
+    }
+    const float* hlast = q.h + (size_t)(D - 1) * P * W;
+    { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
+    { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
+    {
+        const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
+        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
+        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
+    }
+    { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
+    {
+        const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
+        const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
+                                 (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
+        add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
+    }
+    {
+        const int rows[3] = {0, F, 2 * F};
+        const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
+                                 (uint32_t)L.off("flows_alpha.amor_b.weight")};
+        add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
+    }
+}
+
 // per_kslice: one block per existing 64-wide k-slice of every tile (small kernel), else one block per tile
 static void make_blocks(std::vector<DwBlock>& blocks, const std::vector<DwTile>& tiles, int nsplit, int64_t P, int round_to, bool per_kslice) {
     int64_t chunk = (P + nsplit - 1) / nsplit;
@@ -996,42 +1040,7 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     // ---- weight-gradient tile list (pointers depend on the stash allocation)
     if (B.tiles_for != q.h || B.tiles_P != P) {
         std::vector<DwTile> big, small;
-        char key[64];
-        const int one_row[1] = {0};
-        for (int l = 0; l < D; ++l) {
-            std::snprintf(key, sizeof key, "pts_linears.%d.weight", l);
-            const uint32_t dst[1] = {(uint32_t)L.off(key)};
-            const float* dY = q.g_h + (size_t)l * P * W;
-            if (l == 0) {
-                add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
-            } else if (l - 1 == skip) {
-                add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
-                add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
-            } else {
-                add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
-            }
-        }
-        const float* hlast = q.h + (size_t)(D - 1) * P * W;
-        { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
-        { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
-        {
-            const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
-            add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
-            add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
-        }
-        { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
-        {
-            const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
-            const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
-                                     (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
-            add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
-        }
-        {
-            const int rows[3] = {0, F, 2 * F};
-            const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
-                                     (uint32_t)L.off("flows_alpha.amor_b.weight")};
-            add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
-        }
+        build_dw_jobs(c, L, q, P, big, small);
         // split counts: every block of a kernel gets the same number of points; big tiles ~1 block per CU in total,
         // small jobs a finer split (their blocks are short and run several per CU)
         int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, big.size())));
@@ -1151,3 +1160,31 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
 }
 
 }  // extern "C"
+
+// ---- debug / test helper (not part of include/cfnerf.h): the weight-gradient tile plan of a configuration, for the
+// CPU test that every weight element is covered exactly once.  16 int32 per tile:
+// {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[0..3], dst_ld, dst_col, 0, 0} followed by 4 uint32 seg_dst in a second array.
+extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
+    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
+    ParamLayout L = build_layout(*cfg);
+    Stash q;                                   // fake, distinct operand bases: only the geometry is reported
+    float* base = reinterpret_cast<float*>(uintptr_t(1) << 40);
+    const size_t step = size_t(1) << 36;
+    float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
+    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
+    std::vector<DwTile> big, small;
+    build_dw_jobs(*cfg, L, q, P, big, small);
+    for (float** pp : ptrs) *pp = nullptr;     // nothing was allocated: keep ~Stash / release() from freeing the fakes
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (const DwTile& t : (pass == 0 ? big : small)) {
+            if (n >= max_tiles) return -n;
+            int32_t* o = tiles_out + 16 * n;
+            o[0] = pass == 0; o[1] = t.n0; o[2] = t.k0; o[3] = t.N; o[4] = t.K; o[5] = t.gk; o[6] = t.wk; o[7] = t.nseg;
+            for (int g = 0; g < 4; ++g) { o[8 + g] = t.seg_row[g]; segdst_out[4 * n + g] = t.seg_dst[g]; }
+            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = o[15] = 0;
+            ++n;
+        }
+    return n;
+}
+

@@ -159,3 +159,48 @@ def test_seeded_construction_replays_the_reference_rng_stream(golden, tag):
         assert float((f.double() ** 2).sum()) == float(g[f"{tag}.sumsq.{k}"]), k
         n_checked += f.numel()
     assert n_checked == n_params
+
+
+@pytest.mark.parametrize("W,D,ha,hr", [(256, 8, 32, 64), (64, 8, 32, 64), (128, 6, 32, 32), (512, 8, 64, 64), (256, 3, 64, 32), (512, 16, 32, 64)])
+def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
+    """Host logic of the backward: the big / small dW tiles (wave arrangement GN x GK of the small kernel included)
+    must write every live weight element exactly once per split slot and never touch biases or dead tensors."""
+    lib = L.lib()
+    lib.cfnerf_debug_dw_plan.restype = C.c_int
+    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
+    cfg = L.Cfg(D, W, 10, 4, ha, hr, 4)
+    cap = 4096
+    tiles = (C.c_int32 * (16 * cap))()
+    segdst = (C.c_uint32 * (4 * cap))()
+    n = lib.cfnerf_debug_dw_plan(C.byref(cfg), 131072, tiles, segdst, cap)
+    assert n > 0
+    t = np.ctypeslib.as_array(tiles).reshape(cap, 16)[:n]
+    sd = np.ctypeslib.as_array(segdst).reshape(cap, 4)[:n]
+    layout, n_params = cfnerf_amd.param_layout(cfg)
+    count = np.zeros(n_params, np.int32)
+    for row, dst in zip(t, sd):
+        is_big, n0, k0, N, K, gk, wk, nseg = (int(v) for v in row[:8])
+        seg_row = [int(v) for v in row[8:12]]
+        dst_ld, dst_col = int(row[12]), int(row[13])
+        if is_big:
+            rows, cols = 256, 256
+        else:
+            assert gk in (1, 2, 4, 8) and wk in (1, 2)
+            rows, cols = 32 * (8 // gk), 32 * gk * wk
+            assert rows + cols <= 288                      # staged columns: two workgroups (2 x 72 KB of LDS) per CU
+        ns = np.arange(n0, min(N, n0 + rows))
+        ks = np.arange(k0, min(K, k0 + cols))
+        assert len(ns) and len(ks), "empty tile"
+        seg = np.zeros_like(ns)
+        for g in range(1, nseg):
+            seg[ns >= seg_row[g]] = g
+        base = np.array([int(dst[g]) for g in range(4)], np.int64)[seg] + (ns - np.array(seg_row)[seg]) * dst_ld + dst_col
+        idx = (base[:, None] + ks[None, :]).reshape(-1)
+        np.add.at(count, idx, 1)
+    dead = ("alpha_linear.", "alpha_std_linear.", "flows_alpha.amor_d.")
+    for key, (off, numel) in layout.items():
+        c = count[off:off + numel]
+        if key.endswith(".weight") and not key.startswith(dead):
+            assert (c == 1).all(), (key, int(c.min()), int(c.max()))
+        else:
+            assert (c == 0).all(), (key, int(c.max()))
