@@ -60,7 +60,9 @@ class Trainer:
         self.exp_avg_sq = torch.zeros(n, device=dev)
         self.grad = torch.zeros(n, device=dev)
         self.d_ent = torch.tensor([self.beta1 / self.world], device=dev)
-        self.scalars = torch.zeros(4, device=dev)          # loss, loss_nll, mse, psnr (local shard contribution)
+        # loss, loss_nll, mse, psnr of the local shard; loss and loss_nll are CONTRIBUTIONS (nll / (3 N_total) and
+        # beta1 / world on the shard's entropy): their sum over ranks is the global value (RUN:1042-1050)
+        self.scalars = torch.zeros(4, device=dev)
         self.entropy = torch.zeros(1, device=dev)
         self.t = 0
         self._buf_n = None
@@ -106,7 +108,7 @@ class Trainer:
                                       None, L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
                                       None, None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
         L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
-                                        C.c_float(self.beta1), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
+                                        C.c_float(self.beta1 / self.world), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
                 "cfnerf_loss_fwd_bwd")
         L.check(lib.cfnerf_render_bwd(net.handle, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
                                       L.ptr(self.grad), st), "cfnerf_render_bwd")

@@ -255,3 +255,43 @@ def test_depth_gradient_path_matches_oracle():
             assert not g_hip[off:off + cnt].any()
         else:
             grad_close(g_hip[off:off + cnt].reshape(q[key].grad.shape), q[key].grad.numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
+
+
+def test_full_size_train_step_properties_config2():
+    """configs[1] at full size (1024 rays x 128 samples x K=4, W=256), where the oracle is too slow to be the checker:
+    size-independent properties of the train step.
+      * determinism: no atomics, fixed reduction order -> the same step twice gives bit-identical gradients;
+      * shard additivity (the multi-GPU contract): the gradients of the two half batches, each taken with
+        world_size=2 semantics (nll / (3 N_total), beta1 / world on the shard's entropy), sum to the full-batch gradient;
+      * ray-permutation invariance: shuffling the rays of the batch only re-orders the sums."""
+    N, K = 1024, 4
+    cfg = O.OracleCfg(netwidth=256, K_samples=K)
+    _, kw_train, _, model, p, _ = build_model(cfg, 3)
+    rng = np.random.default_rng(17)
+    rays, (H, W, focal) = fern_rays(rng, N)
+    rays = rays.to(DEV)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32, device=DEV)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32, device=DEV)
+    eps = torch.tensor(rng.standard_normal((K, 4)), dtype=torch.float32, device=DEV)
+
+    def grad(sel, world):
+        tr = TR.Trainer(model, beta1=0.01, world_size=world)
+        g = tr.forward_backward(H, W, focal, (rays[0, sel], rays[1, sel]), target[sel].contiguous(), t_rand=t_rand[sel].contiguous(), eps=eps)
+        return g.clone(), tr.scalars.clone()
+
+    full = torch.arange(N, device=DEV)
+    g1, s1 = grad(full, 1)
+    g2, s2 = grad(full, 1)
+    assert torch.equal(g1, g2) and torch.equal(s1, s2), "train step is not deterministic"
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+
+    ga, sa = grad(full[: N // 2], 2)
+    gb, sb = grad(full[N // 2:], 2)
+    scale = float(g1.abs().max())
+    assert float((ga + gb - g1).abs().max()) <= 2e-5 * scale, float((ga + gb - g1).abs().max()) / scale
+    close((sa[:2] + sb[:2]).cpu(), s1[:2].cpu(), atol=1e-5, rtol=1e-5, what="loss, nll: shard sums")
+
+    perm = torch.tensor(rng.permutation(N), device=DEV)
+    gp, sp = grad(perm, 1)
+    assert float((gp - g1).abs().max()) <= 2e-5 * scale, float((gp - g1).abs().max()) / scale
+    close(sp.cpu(), s1.cpu(), atol=1e-5, rtol=1e-5, what="scalars under permutation")
