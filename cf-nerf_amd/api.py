@@ -102,10 +102,20 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     return o, d
 
 
+_T_VALS_CACHE = {}
+
+
 def t_vals_table(device=None) -> torch.Tensor:
-    """The hard-coded 96 + 32 = 128 sample table of RUN:510 (computed on the CPU like the reference)."""
-    t = torch.cat([torch.linspace(0., 0.5, steps=97)[:-1], torch.linspace(0.5, 1., steps=32)], 0)
-    return t.to(device) if device is not None else t
+    """The hard-coded 96 + 32 = 128 sample table of RUN:510 (computed on the CPU like the reference; the device copy
+    is made once per device - treat it as read-only)."""
+    key = str(torch.device(device)) if device is not None else "cpu"
+    t = _T_VALS_CACHE.get(key)
+    if t is None:
+        t = torch.cat([torch.linspace(0., 0.5, steps=97)[:-1], torch.linspace(0.5, 1., steps=32)], 0)
+        if device is not None:
+            t = t.to(device)
+        _T_VALS_CACHE[key] = t
+    return t
 
 
 # --------------------------------------------------------------------------------------------
@@ -329,9 +339,13 @@ class NeRF_Flows(nn.Module):
 
     def eval_eps(self):
         """[K,4] eval latents: the fixed buffers with the LAST sample zeroed (MOD:199,205)."""
-        e = torch.cat([self.sample_rgb, self.sample_alpha], -1).to(torch.float32).clone()
-        e[-1] = 0
-        return e.to(self.device)
+        # the device copy is rebuilt only when the (plain-attribute) latents were replaced or edited in place
+        key = (id(self.sample_rgb), self.sample_rgb._version, id(self.sample_alpha), self.sample_alpha._version)
+        if getattr(self, "_eval_eps_key", None) != key:
+            e = torch.cat([self.sample_rgb, self.sample_alpha], -1).to(torch.float32).clone()
+            e[-1] = 0
+            self._eval_eps_dev, self._eval_eps_key = e.to(self.device), key
+        return self._eval_eps_dev
 
     def draw_eps(self):
         """Fresh train latents in the reference's order: eps_alpha then eps_rgb (MOD:234,246)."""
