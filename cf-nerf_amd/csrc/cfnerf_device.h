@@ -41,6 +41,11 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
 }
 
 // 16*NV MFMAs of one k-chunk (8 k values): a0/a1 = A fragments of the two row tiles, b[j] = B fragments
+#ifdef CFN_ASYM_PRIO
+#define CFN_SETPRIO(x) ((void)0)
+#else
+#define CFN_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #ifndef CFN_MMA_PRIO
 #define CFN_MMA_PRIO 0
 #endif
@@ -65,7 +70,7 @@ template <int NTW, int NV>
 __device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* const (&bp)[NTW], const float* a_ptr,
                                          int lda, int KC) {
     f32x4 bA[NTW], bB[NTW], a0A, a1A, a0B, a1B;
-    __builtin_amdgcn_s_setprio(CFN_MMA_PRIO);
+    CFN_SETPRIO(CFN_MMA_PRIO);
 #pragma unroll
     for (int j = 0; j < NV; ++j) bA[j] = bp[j][0];
     a0A = *reinterpret_cast<const f32x4*>(a_ptr);
@@ -85,7 +90,7 @@ __device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* con
         mma_block<NTW, NV>(acc, a0B, a1B, bB);
     }
     if (kc < KC) mma_block<NTW, NV>(acc, a0A, a1A, bA);       // odd KC tail (operands already loaded)
-    __builtin_amdgcn_s_setprio(CFN_EPI_PRIO);
+    CFN_SETPRIO(CFN_EPI_PRIO);
 }
 
 // acc[i][j] += A[rows i*32..+31][0..8*kc) * B(tile nt0 + j*nts)       (one GEMM segment)
@@ -186,7 +191,7 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* 
             }
     };
     const int last = KC - 1;
-    __builtin_amdgcn_s_setprio(CFN_MMA_PRIO);
+    CFN_SETPRIO(CFN_MMA_PRIO);
 #pragma unroll
     for (int q = 0; q < kPre16; ++q) issue_b(q, min(q, last));
     issue_a(0, 0);
@@ -202,7 +207,7 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* 
             }
         }
     }
-    __builtin_amdgcn_s_setprio(CFN_EPI_PRIO);
+    CFN_SETPRIO(CFN_EPI_PRIO);
 }
 
 template <int NTW, int PRE>
@@ -238,6 +243,26 @@ __device__ __forceinline__ void mma_any(f32x16 (&acc)[2][NTW], const SubL s, int
 }
 
 // streaming (touch-once) global traffic: keep it from evicting the L2-resident packed weights
+// A narrow head (1 or 2 n-tiles) would keep one or two waves busy for the whole K: split K over the waves instead.
+// Wave w takes n-tile w % nt and k-part w / nt of (n_waves / nt) parts; the partial tiles are summed by the caller.
+template <int PREC, int PRE>
+__device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, int wave, int n_waves, const float* __restrict__ wp,
+                                           const __bf16* __restrict__ wp16, const float* lds_a, int lda) {
+    const int lane = lane_id_opaque();
+    const int ntc = (int)s.nt, nt = wave % ntc, part = wave / ntc, nparts = n_waves / ntc;
+    if (PREC == PREC_BF16X3) {
+        const int KC = s.kc16, kcp = KC / nparts, k0 = part * kcp;
+        const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5) + k0 * 16;
+        const bf16x8* bp[1] = {reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + ((size_t)nt * KC + k0) * 128 + lane};
+        mma_loop16<1, 1, PRE>(acc, bp, a_ptr, lda, kcp);
+    } else {
+        const int KC = s.kc, kcp = KC / nparts, k0 = part * kcp;
+        const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5) + k0 * 8;
+        const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(wp + s.w_off) + ((size_t)nt * KC + k0) * 64 + lane};
+        mma_loop<1, 1>(acc, bp, a_ptr, lda, kcp);
+    }
+}
+
 __device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
 
@@ -248,11 +273,22 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 
 // Write acc (+bias, activation) to the LDS tile (row-major, stride ld, column offset col0) and
 // optionally to a row-major global stash (stride gld) for rows < rows_valid.
+// bias of this lane's column in each of the wave's n-tiles, fetched BEFORE the MFMA loop so its L2 latency hides under it
+template <int NTW>
+__device__ __forceinline__ void load_bias(const SubL s, int nt0, int nts, const float* __restrict__ wp, float (&bv)[NTW]) {
+    const int lane = lane_id_opaque();
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = nt0 + j * nts;
+        bv[j] = (nt < (int)s.nt && s.b_off != 0xffffffffu) ? wp[s.b_off + nt * 32 + (lane & 31)] : 0.f;
+    }
+}
+
 template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                             float* __restrict__ gdst, int gld, int rows_valid,
-                                            uint32_t* __restrict__ mbits = nullptr) {
+                                            uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -260,7 +296,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
         const int nt = nt0 + j * nts;
         if (nt >= (int)s.nt) continue;
         const int col = nt * 32 + (lane & 31);
-        const float bv = (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
+        const float bv = bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
         float* lp = lds_dst + rbase * ld + col0 + col;
         float* gp = (gdst != nullptr) ? gdst + (size_t)rbase * gld + col : nullptr;
         uint32_t bits = 0;

@@ -53,6 +53,13 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
     }
 }
 
+#ifdef CFN_TIMESTAMP
+__device__ unsigned long long g_dbg[4096];     // [0,2048): per-WG start/end/placement; [2048,..): per-layer marks of WG 0 and WG grid/2
+extern "C" int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
+}
+#endif
+
 template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
 __global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
 void fused_fwd_kernel(const FwdArgs A) {
@@ -83,6 +90,17 @@ void fused_fwd_kernel(const FwdArgs A) {
     const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
     const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
 
+#ifdef CFN_ASYM_PRIO
+    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef CFN_TIMESTAMP
+    const unsigned long long t_start = wall_clock64();
+    int dbg_n = 0;
+    const int dbg_sel = (blockIdx.x == 0) ? 0 : (blockIdx.x == (gridDim.x >> 1)) ? 1 : -1;
+#define CFN_MARK() do { if (dbg_sel >= 0 && tid == 0 && dbg_n < 700) g_dbg[2048 + dbg_sel * 700 + dbg_n++] = wall_clock64(); } while (0)
+#else
+#define CFN_MARK() ((void)0)
+#endif
     for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         float ro[3], rd[3], nearv = 0.f, farv = 1.f, dnorm = 0.f;
         if (MODE == 0) {
@@ -140,6 +158,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 __syncthreads();
             }
 
+            CFN_MARK();                              // sampling done
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             if (A.st_enc != nullptr) {
@@ -151,11 +170,16 @@ void fused_fwd_kernel(const FwdArgs A) {
             }
             __syncthreads();
 
+            CFN_MARK();                              // encoding done
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
                 acc_zero(acc);
+                float bias[C::NTW];
+                load_bias<C::NTW>(T.trunk[l], wave, kWaves, wp, bias);
+                CFN_MARK();                          // MFMA phase of layer l starts
                 mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
+                CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
                     encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
@@ -165,24 +189,50 @@ void fused_fwd_kernel(const FwdArgs A) {
                 __syncthreads();
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb, bias);
                 __syncthreads();
+                CFN_MARK();                          // epilogue + barrier done
             }
 
-            // ---- 4. heads: h_alpha = A h (MOD:175), feature = F h (MOD:176)
+            // ---- 4. heads: h_alpha = A h (MOD:175), feature = F h (MOD:176).  h_alpha is only 1-2 n-tiles wide: its K is
+            //         split over the 4 waves (a quarter or half each) and the partial tiles are summed through act[] once
+            //         h is dead, instead of one wave grinding through the whole K while three wait.
             {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
                 acc_zero(accF); acc_zero(accA);
-                mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
+                float biasF[C::NTW];
+                load_bias<C::NTW>(T.ft, wave, kWaves, wp, biasF);
+                mma_ksplit<PREC, (W > 256 ? 3 : 2)>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
                 mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
+                __syncthreads();                     // every wave is done reading h
+                {
+                    const int lo = lane_id_opaque();
+                    float* lp = act + (4 * (lo >> 5)) * LD + 32 * wave + (lo & 31);      // raw fp32 partial of wave w: act[:, 32w..32w+32)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) lp[(i * 32 + (r & 3) + 8 * (r >> 2)) * LD] = accA[i][0][r];
+                }
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC>(accA, T.ha, wave, kWaves, wp, hs, HLD, 0,
-                                         A.st_ha ? A.st_ha + p0 * HA : nullptr, HA, rows_valid);
+                {
+                    const int ntc = (int)T.ha.nt, nparts = kWaves / ntc;
+                    for (int idx = tid; idx < kTileM * HA; idx += kThreads) {
+                        const int row = idx / HA, c = idx - row * HA;
+                        const float* pp = act + row * LD + 32 * (c >> 5) + (c & 31);     // wave w = part * ntc + n-tile
+                        float v = pp[0];
+                        for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
+                        v += wp[T.ha.b_off + c];
+                        act_store<PREC>(hs + row * HLD + c, v);
+                        if (A.st_ha != nullptr && row < rows_valid) st_stream(A.st_ha + (p0 + row) * HA + c, v);
+                    }
+                }
+                __syncthreads();
                 store_tiles<C::NTW, ACT_NONE, PREC>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
-                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
+                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid, nullptr, biasF);
                 __syncthreads();
             }
+            CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
             {
                 f32x16 acc[2][C::NTV];
@@ -205,6 +255,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
+            CFN_MARK();                              // views done
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 f32x16 acc[2][1];
@@ -215,6 +266,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
+            CFN_MARK();                              // h_rgb done
             // ---- 7. amortised flow parameters (MOD:366-383), once per point (the reference recomputes
             //         them K times on duplicated rows, MOD:210-217): theta -> act[:, 0:128)
             {
@@ -247,6 +299,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     }
                 __syncthreads();
             }
+            CFN_MARK();                              // theta done
             // ---- 8. flows + composite: lane = sample (row), waves stride over the K latent samples
             {
                 const int row = lane_id_opaque();
@@ -314,6 +367,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 }
             }
             __syncthreads();
+            CFN_MARK();                              // flows + composite done
         }  // chunks
 
         if (MODE == 0 && tid < K) {
@@ -353,6 +407,14 @@ void fused_fwd_kernel(const FwdArgs A) {
         __syncthreads();
     }  // units
 
+#ifdef CFN_TIMESTAMP
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_dbg[blockIdx.x * 4 + 0] = t_start;
+        g_dbg[blockIdx.x * 4 + 1] = wall_clock64();
+        g_dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((15 << 11) | 4);      // HW_ID[15:0]
+        g_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // XCC_ID
+    }
+#endif
     if (TRAIN && A.ent_partials != nullptr) {
         const float sr = wave_sum(ent_r_sum), sa = wave_sum(ent_a_sum);
         if (lane == 0) { red[wave * 2] = sr; red[wave * 2 + 1] = sa; }
@@ -652,6 +714,9 @@ static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hip
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         per_cu = max_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
+#ifdef CFN_FWD_MAX_PER_CU
+        if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
+#endif
         if (per_cu > 2) per_cu = 2;
         lds_set = lds;
     }
