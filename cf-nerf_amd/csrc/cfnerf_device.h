@@ -284,11 +284,15 @@ __device__ __forceinline__ void load_bias(const SubL s, int nt0, int nts, const 
     }
 }
 
-template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false>
-__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
-                                            const float* __restrict__ wp, float* lds_dst, int ld, int col0,
-                                            float* __restrict__ gdst, int gld, int rows_valid,
-                                            uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
+// epilogue of a layer: bias + activation -> LDS tile (and, in the train variants, the activation stash in HBM).
+// STASH is 0 (no stash code at all: the eval variants), 1 (stash every row: the wave-uniform common case of a full
+// tile) or 2 (ragged last tile: per-row check); store_tiles picks 1 / 2 / 0 from gdst and rows_valid once per call, so
+// the per-element work is add, max, ds_write (+ one non-temporal store) with no exec-mask juggling.
+template <int NTW, int ACT, int PREC, bool WANT_BITS, int STASH>
+__device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
+                                                 const float* __restrict__ wp, float* lds_dst, int ld, int col0,
+                                                 float* __restrict__ gdst, int gld, int rows_valid,
+                                                 uint32_t* __restrict__ mbits, const float* bias_pre) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -298,7 +302,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
         const int col = nt * 32 + (lane & 31);
         const float bv = bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
         float* lp = lds_dst + rbase * ld + col0 + col;
-        float* gp = (gdst != nullptr) ? gdst + (size_t)rbase * gld + col : nullptr;
+        float* gp = STASH ? gdst + (size_t)rbase * gld + col : nullptr;
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -308,12 +312,26 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
                 float v = acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                 act_store<PREC>(lp + rr * ld, v);
-                if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * gld, v);
+                if (STASH == 1) st_stream(gp + rr * gld, v);
+                if (STASH == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * gld, v); }
                 if (WANT_BITS) bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
         if (WANT_BITS && mbits != nullptr) mbits[nt * 64 + lane] = bits;
+    }
+}
+
+template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false, bool MAY_STASH = true>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
+                                            const float* __restrict__ wp, float* lds_dst, int ld, int col0,
+                                            float* __restrict__ gdst, int gld, int rows_valid,
+                                            uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
+    if (MAY_STASH && gdst != nullptr) {
+        if (rows_valid >= 64) store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+        else                  store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 2>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+    } else {
+        store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 0>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
     }
 }
 

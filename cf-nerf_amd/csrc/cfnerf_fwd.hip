@@ -98,8 +98,14 @@ void fused_fwd_kernel(const FwdArgs A) {
     int dbg_n = 0;
     const int dbg_sel = (blockIdx.x == 0) ? 0 : (blockIdx.x == (gridDim.x >> 1)) ? 1 : -1;
 #define CFN_MARK() do { if (dbg_sel >= 0 && tid == 0 && dbg_n < 700) g_dbg[2048 + dbg_sel * 700 + dbg_n++] = wall_clock64(); } while (0)
+#ifdef CFN_TIMESTAMP_FINE
+#define CFN_MARK2() CFN_MARK()
+#else
+#define CFN_MARK2() ((void)0)
+#endif
 #else
 #define CFN_MARK() ((void)0)
+#define CFN_MARK2() ((void)0)
 #endif
     for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         float ro[3], rd[3], nearv = 0.f, farv = 1.f, dnorm = 0.f;
@@ -187,9 +193,11 @@ void fused_fwd_kernel(const FwdArgs A) {
                     mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.skipseg, wave, kWaves, wp, wp16, act, LD);
                 }
                 __syncthreads();
+                CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb, bias);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb, bias);
+                CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
                 CFN_MARK();                          // epilogue + barrier done
             }
@@ -228,7 +236,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     }
                 }
                 __syncthreads();
-                store_tiles<C::NTW, ACT_NONE, PREC>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid, nullptr, biasF);
                 __syncthreads();
             }
@@ -251,7 +259,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
@@ -262,7 +270,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 acc_zero(acc);
                 mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
+                store_tiles<1, ACT_NONE, PREC, false, TRAIN>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }

@@ -1,0 +1,28 @@
+import ctypes as C, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import cfnerf_amd
+from cfnerf_amd import _lib as L
+from oracle import cfnerf_oracle as O
+from util_hip import build_model, fern_rays
+cfg = O.OracleCfg(netwidth=256, K_samples=4)
+_, kw_train, kw_test, model, _, _ = build_model(cfg, 0)
+rays, (H, W, focal) = fern_rays(np.random.default_rng(0), 1024)
+rays = rays.cuda()
+for _ in range(3):
+    with torch.no_grad(): cfnerf_amd.render(H, W, focal, rays=rays, **kw_test)
+torch.cuda.synchronize()
+lib = L.lib()
+big = (C.c_ulonglong * 4096)()
+lib.cfnerf_debug_read_dbg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+assert lib.cfnerf_debug_read_dbg(big, 4096) == 0
+m = np.ctypeslib.as_array(big).astype(np.int64)
+t = m[2048:2048 + 2 + 8 * 5].astype(np.float64); t = (t - t[0]) / 100.0
+d = np.diff(t)
+print("sampling->encode", d[0])
+tr = d[1:1 + 40].reshape(8, 5) if len(d) >= 41 else None
+lay = np.diff(np.concatenate([[t[1]], t[2:42]])).reshape(8, 5)
+print("per layer [wait, mfma(wave0), barrier1 wait, store(wave0), barrier2 wait] us:")
+print(np.round(lay, 2))
+print("mean", np.round(lay[1:].mean(0), 2))
