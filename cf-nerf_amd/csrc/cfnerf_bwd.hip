@@ -276,10 +276,11 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int n
 }
 
 // acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials
-template <int NTW, int PREC>
-__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
-                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
-                                          int rows_valid) {
+// FULL: every row of the tile exists (the wave-uniform common case) - no per-element exec-mask code
+template <int NTW, int PREC, bool FULL>
+__device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                               float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                               int rows_valid) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -296,15 +297,24 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = rr + rbase < rows_valid;
+                const bool ok = FULL || (rr + rbase < rows_valid);
                 const float v = (ok && ((mb >> (i * 16 + r)) & 1u)) ? acc[i][j][r] : 0.f;
                 act_store<PREC>(lp + rr * ld, v);
-                if (ok) st_stream(gp + (size_t)rr * gld, v);
+                if (FULL) st_stream(gp + (size_t)rr * gld, v);
+                else if (ok) st_stream(gp + (size_t)rr * gld, v);
                 csum += v;
             }
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }
+}
+
+template <int NTW, int PREC>
+__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                          int rows_valid) {
+    if (rows_valid >= 64) store_bwd_impl<NTW, PREC, true>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
+    else                  store_bwd_impl<NTW, PREC, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
 }
 
 template <int W, int PREC>
