@@ -294,17 +294,26 @@ void fused_fwd_kernel(const FwdArgs A) {
                 const int F = 4;
                 const bool tanh_col = is_rgb ? (c_local >= 9 * F && c_local < 15 * F) : (c_local < 2 * F);
                 float* lp = act + rbase * LD + colb + cl;
-                float* gp = (A.st_theta != nullptr) ? A.st_theta + (p0 + rbase) * kThetaAll + colb + cl : nullptr;
+                float* gp = (TRAIN && A.st_theta != nullptr) ? A.st_theta + (p0 + rbase) * kThetaAll + colb + cl : nullptr;
+                // stash mode picked once (wave-uniform): 0 none, 1 every row (full tile), 2 ragged last tile
+                const int stash_mode = (gp == nullptr) ? 0 : (rows_valid >= kTileM ? 1 : 2);
+                auto theta_out = [&](auto mode) {
+                    constexpr int M = decltype(mode)::value;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][0][r] + bv;
-                        if (tanh_col) v = tanhf(v);                   // diag_activation, MOD:337-348
-                        lp[rr * LD] = v;
-                        if (gp != nullptr && rr + rbase < rows_valid) st_stream(gp + rr * kThetaAll, v);
-                    }
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                            float v = acc[i][0][r] + bv;
+                            if (tanh_col) v = tanhf(v);               // diag_activation, MOD:337-348
+                            lp[rr * LD] = v;
+                            if (M == 1) st_stream(gp + rr * kThetaAll, v);
+                            if (M == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * kThetaAll, v); }
+                        }
+                };
+                if (stash_mode == 0) theta_out(std::integral_constant<int, 0>{});
+                else if (stash_mode == 1) theta_out(std::integral_constant<int, 1>{});
+                else theta_out(std::integral_constant<int, 2>{});
                 __syncthreads();
             }
             CFN_MARK();                              // theta done
