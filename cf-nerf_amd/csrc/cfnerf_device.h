@@ -30,6 +30,18 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // (row stride = 16 B mod 256 B) and rows 16-B aligned.  >= 128 so the theta tile fits.
 __host__ __device__ constexpr int act_ld(int W) { return (W > kThetaAll ? W : kThetaAll) + 4; }
 
+// accumulators start at the bias of the lane's column: the epilogue then needs no add (a lane's 32 fragment values of a
+// tile all belong to one output column)
+template <int NTW>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NTW], const float (&bias)[NTW]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bias[j];
+}
+
 template <int NTW>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
 #pragma unroll
@@ -288,7 +300,7 @@ __device__ __forceinline__ void load_bias(const SubL s, int nt0, int nts, const 
 // STASH is 0 (no stash code at all: the eval variants), 1 (stash every row: the wave-uniform common case of a full
 // tile) or 2 (ragged last tile: per-row check); store_tiles picks 1 / 2 / 0 from gdst and rows_valid once per call, so
 // the per-element work is add, max, ds_write (+ one non-temporal store) with no exec-mask juggling.
-template <int NTW, int ACT, int PREC, bool WANT_BITS, int STASH>
+template <int NTW, int ACT, int PREC, bool WANT_BITS, int STASH, bool BIAS_IN_ACC>
 __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                                  const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                                  float* __restrict__ gdst, int gld, int rows_valid,
@@ -300,7 +312,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
         const int nt = nt0 + j * nts;
         if (nt >= (int)s.nt) continue;
         const int col = nt * 32 + (lane & 31);
-        const float bv = bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
+        const float bv = BIAS_IN_ACC ? 0.f : bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
         float* lp = lds_dst + rbase * ld + col0 + col;
         float* gp = STASH ? gdst + (size_t)rbase * gld + col : nullptr;
         uint32_t bits = 0;
@@ -309,7 +321,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
-                float v = acc[i][j][r] + bv;
+                float v = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                 act_store<PREC>(lp + rr * ld, v);
                 if (STASH == 1) st_stream(gp + rr * gld, v);
@@ -322,16 +334,16 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
     }
 }
 
-template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false, bool MAY_STASH = true>
+template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false, bool MAY_STASH = true, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                             float* __restrict__ gdst, int gld, int rows_valid,
                                             uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
     if (MAY_STASH && gdst != nullptr) {
-        if (rows_valid >= 64) store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
-        else                  store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 2>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+        if (rows_valid >= 64) store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+        else                  store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 2, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
     } else {
-        store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 0>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+        store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 0, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
     }
 }
 

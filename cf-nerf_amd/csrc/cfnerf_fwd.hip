@@ -195,9 +195,9 @@ void fused_fwd_kernel(const FwdArgs A) {
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
-                acc_zero(acc);
                 float bias[C::NTW];
                 load_bias<C::NTW>(T.trunk[l], wave, kWaves, wp, bias);
+                acc_init(acc, bias);
                 CFN_MARK();                          // MFMA phase of layer l starts
                 mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
                 CFN_MARK();                          // ... ends for wave 0
@@ -211,7 +211,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb, bias);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
                 CFN_MARK();                          // epilogue + barrier done
@@ -223,9 +223,9 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
-                acc_zero(accF); acc_zero(accA);
                 float biasF[C::NTW];
                 load_bias<C::NTW>(T.ft, wave, kWaves, wp, biasF);
+                acc_init(accF, biasF); acc_zero(accA);
                 mma_ksplit<PREC, (W > 256 ? 3 : 2)>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
                 mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
@@ -251,15 +251,17 @@ void fused_fwd_kernel(const FwdArgs A) {
                     }
                 }
                 __syncthreads();
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
-                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid, nullptr, biasF);
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN, true>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
+                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
             }
             CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
             {
                 f32x16 acc[2][C::NTV];
-                acc_zero(acc);
+                float bias[C::NTV];
+                load_bias<C::NTV>(T.vf, wave, kWaves, wp, bias);
+                acc_init(acc, bias);
                 mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vf, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
@@ -274,7 +276,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
@@ -282,10 +284,12 @@ void fused_fwd_kernel(const FwdArgs A) {
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 f32x16 acc[2][1];
-                acc_zero(acc);
+                float bias[1];
+                load_bias<1>(T.hr, wave, kWaves, wp, bias);
+                acc_init(acc, bias);
                 mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC, false, TRAIN>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
+                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
