@@ -296,6 +296,10 @@ __device__ __forceinline__ void load_bias(const SubL s, int nt0, int nts, const 
     }
 }
 
+// ReLU as ONE integer max on the bit pattern (negative floats and -0 are negative ints -> +0): fmaxf costs two v_max
+// (the compiler first quiets a possible signalling NaN of the MFMA result with max(x, x))
+__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
 // epilogue of a layer: bias + activation -> LDS tile (and, in the train variants, the activation stash in HBM).
 // STASH is 0 (no stash code at all: the eval variants), 1 (stash every row: the wave-uniform common case of a full
 // tile) or 2 (ragged last tile: per-row check); store_tiles picks 1 / 2 / 0 from gdst and rows_valid once per call, so
@@ -322,7 +326,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
                 float v = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
-                if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                if (ACT == ACT_RELU) v = relu_f(v);
                 act_store<PREC>(lp + rr * ld, v);
                 if (STASH == 1) st_stream(gp + rr * gld, v);
                 if (STASH == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * gld, v); }
