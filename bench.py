@@ -146,7 +146,9 @@ def main():
         raise SystemExit("train mode requested but the backward kernels are not built")
 
     torch.manual_seed(0)                        # same random-init weights on every rank (nn.Linear-style init of the product)
-    kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=W, netdepth=D, K_samples=K, device=dev))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):                # create_nerf prints the reference's "No reloading" notice
+        kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=W, netdepth=D, K_samples=K, device=dev))
     model = kw_train["network_fn"]
     net = model.module
     rays, target, (H, Wd, focal) = synth_batch(rank, N_RAND, dev)
@@ -249,9 +251,22 @@ def main():
             out["alt_precision"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode)
-        print(json.dumps(out), flush=True)
+    # the JSON line is the LAST thing on stdout: RCCL prints its version banner through libc's buffered stdout (it would
+    # otherwise surface at process exit, after the line), so every rank flushes that before the final barrier
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+    flush_c_stdio()
     if world > 1 or force_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
