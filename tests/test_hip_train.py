@@ -295,3 +295,45 @@ def test_full_size_train_step_properties_config2():
     gp, sp = grad(perm, 1)
     assert float((gp - g1).abs().max()) <= 2e-5 * scale, float((gp - g1).abs().max()) / scale
     close(sp.cpu(), s1.cpu(), atol=1e-5, rtol=1e-5, what="scalars under permutation")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_configurations_forward_and_gradients_vs_oracle(seed):
+    """Seeded random draw over the supported configuration space (width, depth, K, head sizes, batch, NDC / lindisp /
+    white background, jitter on or off): render outputs, loss and every gradient against the CPU oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    W = int(rng.choice([64, 128, 256]))
+    D = int(rng.choice([4, 6, 8]))
+    K = int(rng.integers(2, 7))
+    ha, hr = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
+    N = int(rng.integers(3, 24))
+    ndc = bool(rng.integers(0, 2))
+    lindisp = (not ndc) and bool(rng.integers(0, 2))
+    wb = bool(rng.integers(0, 2))
+    perturb = bool(rng.integers(0, 4))                   # mostly on
+    cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr)
+    _, kw_train, _, model, p, _ = build_model(cfg, 700 + seed, no_ndc=not ndc, lindisp=lindisp, white_bkgd=wb)
+    net = model.module
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    near, far = (0., 1.) if ndc else (1.2, 8.0)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32) if perturb else None
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    beta1 = float(rng.choice([0.0, 0.01, 0.1]))
+    tr = TR.Trainer(net, beta1=beta1)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=None if t_rand is None else t_rand.to(DEV),
+                               eps=torch.cat([er, ea], -1).to(DEV), near=near, far=far, ndc=ndc, lindisp=lindisp, white_bkgd=wb,
+                               perturb=1. if perturb else 0.).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
+    scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb)
+    what = f"[W={W} D={D} K={K} ha={ha} hr={hr} N={N} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
+    close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map " + what)
+    close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)
+    for key, (off, cnt) in net.layout.items():
+        if grads[key] is None:
+            assert not grad[off:off + cnt].any(), key
+        else:
+            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key + " " + what,
+                       n_flip_tol=40.0 / (N * 128))
