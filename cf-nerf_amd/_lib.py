@@ -36,7 +36,10 @@ _SIGS = {
     "cfnerf_network_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
     "cfnerf_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "cfnerf_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_int64, _P, _P, _P]),
-    "cfnerf_render_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "cfnerf_workspace_bytes": (C.c_int64, [C.POINTER(Cfg), C.c_int64, C.c_int, C.c_int]),
+    "cfnerf_model_set_workspace": (C.c_int, [_P, _P, C.c_size_t]),
+    "cfnerf_model_stash_generation": (C.c_uint64, [_P]),
+    "cfnerf_render_bwd": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     "cfnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "cfnerf_model_set_precision": (C.c_int, [_P, C.c_int]),
     "cfnerf_model_workspace_bytes": (C.c_int64, [_P]),

@@ -56,16 +56,13 @@ class Embedder:
         self.freq_bands = 2. ** torch.linspace(0., multires - 1, steps=multires)     # HLP:38
 
     def embed(self, inputs: torch.Tensor) -> torch.Tensor:
-        if inputs.is_cuda and inputs.shape[-1] == 3:                                  # the HIP kernel (cfnerf_embed)
-            x = _f32c(inputs.reshape(-1, 3))
-            out = torch.empty(x.shape[0], self.out_dim, device=x.device)
-            L.check(L.lib().cfnerf_embed(L.ptr(x), x.shape[0], self.multires, L.ptr(out), L.stream()), "cfnerf_embed")
-            return out.reshape(list(inputs.shape[:-1]) + [self.out_dim])
-        out = [inputs]                                                                # CPU tensors: plain torch, like the reference
-        for f in self.freq_bands.tolist():                                            # HLP:42-45
-            out.append(torch.sin(inputs * f))
-            out.append(torch.cos(inputs * f))
-        return torch.cat(out, -1)                                                     # HLP:51
+        _need_gpu(inputs, "Embedder input")                                           # HIP kernel only (cfnerf_embed)
+        if inputs.shape[-1] != self.input_dims or self.input_dims != 3:
+            raise ValueError("Embedder encodes 3-vectors (HLP:57-64: input_dims = 3)")
+        x = _f32c(inputs.reshape(-1, 3))
+        out = torch.empty(x.shape[0], self.out_dim, device=x.device)
+        L.check(L.lib().cfnerf_embed(L.ptr(x), x.shape[0], self.multires, L.ptr(out), L.stream()), "cfnerf_embed")
+        return out.reshape(list(inputs.shape[:-1]) + [self.out_dim])
 
 
 def get_embedder(multires, i=0):
@@ -236,8 +233,9 @@ class NeRF_Flows(nn.Module):
         if not self.use_viewdirs:
             # the reference crashes later with an AttributeError (MOD:63-64,183-186); reject up front
             raise ValueError("use_viewdirs=False is not supported (the reference's NeRF_Flows cannot run it either)")
-        if list(self.skips) != [self.D / 2] and list(self.skips) != [self.D // 2]:
-            raise ValueError(f"skips must be [netdepth/2] (RUN:327), got {self.skips}")
+        if list(self.skips) != [self.D / 2]:
+            # the float division matters: for an odd netdepth nothing matches `i in skips` and there is no skip concat
+            raise ValueError(f"skips must be [netdepth / 2] (RUN:327), got {self.skips}")
         if (self.input_ch - 3) % 6 or (self.input_ch_views - 3) % 6:
             raise ValueError("input_ch / input_ch_views must come from get_embedder (3 + 6*multires)")
         self.cfg = _cfg_struct(self.D, self.W, (self.input_ch - 3) // 6, (self.input_ch_views - 3) // 6,
@@ -251,6 +249,8 @@ class NeRF_Flows(nn.Module):
         L.check(L.lib().cfnerf_model_create(C.byref(self.cfg), C.byref(h)), "cfnerf_model_create")
         self._h = h
         self._packed_version = None
+        self._next_eps = None          # explicit latents handed from render_rays to an unfused network_query_fn
+        self._ws = None                # train-step workspace: a torch-owned block lent to the library
 
     # ---- parameters ------------------------------------------------------------------------
     def view(self, key: str) -> torch.Tensor:
@@ -331,6 +331,28 @@ class NeRF_Flows(nn.Module):
     def handle(self):
         return self._h
 
+    def ensure_workspace(self, N: int, S: int, K: int):
+        """Lend the library a torch-owned block big enough for a STASH forward + backward of an (N,S,K) batch
+        (``cfnerf_workspace_bytes`` / ``cfnerf_model_set_workspace``): the library itself never allocates on the train
+        path.  The block only grows; a pending backward of an earlier forward is invalidated when it does."""
+        lib = L.lib()
+        need = lib.cfnerf_workspace_bytes(C.byref(self.cfg), N, S, K)
+        if need < 0:
+            raise RuntimeError("cfnerf_workspace_bytes: " + lib.cfnerf_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            L.check(lib.cfnerf_model_set_workspace(self._h, None, 0), "cfnerf_model_set_workspace")   # drop the old block first
+            self._ws = None
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(lib.cfnerf_model_set_workspace(self._h, C.c_void_p(ws.data_ptr()), ws.numel()), "cfnerf_model_set_workspace")
+            self._ws = ws
+
+    def release_workspace(self):
+        """Give the block back (e.g. before a large evaluation render)."""
+        if self._ws is not None:
+            torch.cuda.synchronize(self.device)
+            L.check(L.lib().cfnerf_model_set_workspace(self._h, None, 0), "cfnerf_model_set_workspace")
+            self._ws = None
+
     def set_precision(self, mode: str):
         """'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (opt-in split-bf16 MFMA in the forward's dense layers)."""
         code = {"fp32": 0, "bf16x3": 1}[mode]
@@ -365,6 +387,8 @@ class NeRF_Flows(nn.Module):
         P, K = xf.shape[0], self.K_samples
         if eps_alpha is not None or eps_rgb is not None:
             eps = torch.cat([eps_rgb, eps_alpha], -1).to(self.device, torch.float32).contiguous()
+        elif self._next_eps is not None:                            # latents chosen by the enclosing render_rays call
+            eps = self._next_eps
         else:
             eps = self.eval_eps() if is_test else self.draw_eps()
         raw = torch.empty(P, K, 4, device=self.device, dtype=torch.float32)
@@ -380,7 +404,7 @@ class NeRF_Flows(nn.Module):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             try:
-                L.lib().cfnerf_model_destroy(h)
+                L.lib().cfnerf_model_destroy(h)      # synchronises the device before the lent workspace tensor is freed
             except Exception:
                 pass
             self._h = None
@@ -454,11 +478,13 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
 
 # --------------------------------------------------------------------------------------------
 class _RenderFn(torch.autograd.Function):
-    """Fused render (forward with activation stash) + cfnerf_render_bwd."""
+    """Fused render (forward with activation stash) + cfnerf_render_bwd.  The model has ONE stash: the node remembers
+    the generation of its forward and the backward is refused (loudly) if a later grad-enabled forward replaced it."""
 
     @staticmethod
-    def forward(ctx, flat, model, rays, t_vals, t_rand, eps, flags, want_pts):
-        N, S, K = rays.shape[0], t_vals.shape[0], eps.shape[0]
+    def forward(ctx, flat, model, rays, t_vals, t_rand, eps, flags, want_pts, z_vals):
+        N, K = rays.shape[0], eps.shape[0]
+        S = z_vals.shape[1] if z_vals is not None else t_vals.shape[0]
         dev = rays.device
         rgb_map = torch.empty(N, 3, K, device=dev)
         disp = torch.empty(N, K, device=dev)
@@ -466,11 +492,15 @@ class _RenderFn(torch.autograd.Function):
         raw = torch.empty(N, S, K, 4, device=dev)
         pts = torch.empty(N, S, 3, device=dev) if want_pts else None
         ent = torch.zeros(1, device=dev)
-        L.check(L.lib().cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), None, L.ptr(eps), N, S, K,
-                                          flags | L.F_STASH, L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), None,
-                                          L.ptr(pts), None, L.ptr(ent), L.stream()), "cfnerf_render_fwd")
+        lib = L.lib()
+        model.ensure_workspace(N, S, K)
+        L.check(lib.cfnerf_render_fwd(model.handle, L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.ptr(z_vals), L.ptr(eps), N, S, K,
+                                      flags | L.F_STASH, L.ptr(rgb_map), L.ptr(disp), L.ptr(depth), L.ptr(raw), None,
+                                      L.ptr(pts), None, L.ptr(ent), L.stream()), "cfnerf_render_fwd")
         ctx.model = model
         ctx.n_params = flat.numel()
+        ctx.generation = lib.cfnerf_model_stash_generation(model.handle)
+        ctx.shape = (N, 3, K)
         ctx.mark_non_differentiable(disp, raw)
         if pts is None:
             pts = torch.empty(0, device=dev)
@@ -482,12 +512,12 @@ class _RenderFn(torch.autograd.Function):
         model = ctx.model
         dev = model.flat.device
         grad = torch.empty(ctx.n_params, device=dev)
-        d_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(model._last_shape, device=dev)
+        d_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(ctx.shape, device=dev)
         dd = _f32c(d_depth) if d_depth is not None else None
         de = _f32c(d_ent.reshape(1)) if d_ent is not None else None
-        L.check(L.lib().cfnerf_render_bwd(model.handle, L.ptr(d_rgb), L.ptr(dd), L.ptr(de), L.ptr(grad), L.stream()),
+        L.check(L.lib().cfnerf_render_bwd(model.handle, ctx.generation, L.ptr(d_rgb), L.ptr(dd), L.ptr(de), L.ptr(grad), L.stream()),
                 "cfnerf_render_bwd")
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, uniformsample, retraw=False,
@@ -540,8 +570,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, is_train, un
         return _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_rand, eps, is_train, lindisp, white_bkgd)
 
     if is_train and N > 0 and torch.is_grad_enabled() and model.flat.requires_grad:
-        model._last_shape = (N, 3, K)
-        rgb_map, disp, depth, ent, raw, pts = _RenderFn.apply(model.flat, model, rays, t_vals, t_rand, eps, flags, True)
+        rgb_map, disp, depth, ent, raw, pts = _RenderFn.apply(model.flat, model, rays, t_vals, t_rand, eps, flags, True, None)
         return {'rgb_map': rgb_map, 'disp_map': disp, 'depth_map': depth, 'raw': raw,
                 'loss_entropy': ent.reshape(1, 1, 1).expand(N * S, K, 1), 'pts': pts}
 
@@ -620,8 +649,11 @@ def _render_rays_unfused(rays, model, network_fn, network_query_fn, t_vals, t_ra
     pts0 = torch.empty(N, S, 3, device=rays.device)
     L.check(L.lib().cfnerf_sample_points(L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), L.F_LINDISP if lindisp else 0, N, S, L.ptr(z_vals),
                                          L.ptr(pts0), L.stream()), "cfnerf_sample_points")            # RUN:510-534
-    model._next_eps = eps
-    raw, loss_entropy = network_query_fn(pts0, viewdirs, network_fn, is_val=False, is_test=not is_train)
+    model._next_eps = eps                    # NeRF_Flows.forward consumes it: a custom query fn honours the explicit latents too
+    try:
+        raw, loss_entropy = network_query_fn(pts0, viewdirs, network_fn, is_val=False, is_test=not is_train)
+    finally:
+        model._next_eps = None               # never leaks into a later direct call
     rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, 0., white_bkgd)
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'depth_map': depth_map}
     if is_train:
@@ -739,10 +771,7 @@ def create_nerf(args):
     grad_vars = list(model.parameters())
 
     def network_query_fn(inputs, viewdirs, network_fn, is_val, is_test):
-        m = _unwrap(network_fn)
-        eps = getattr(m, "_next_eps", None)
-        fn = (lambda x, iv, it: m(x, iv, it, eps_alpha=eps[:, 3:4], eps_rgb=eps[:, 0:3])) if eps is not None else network_fn
-        return run_network(inputs, viewdirs, fn, is_val, is_test, embed_fn=args.embed_fn,
+        return run_network(inputs, viewdirs, network_fn, is_val, is_test, embed_fn=args.embed_fn,
                            embeddirs_fn=args.embeddirs_fn, netchunk=args.netchunk_per_gpu * max(1, getattr(args, "n_gpus", 1)))
     network_query_fn._cfnerf_fused = True        # render_rays may replace query + composite by the fused launch
 

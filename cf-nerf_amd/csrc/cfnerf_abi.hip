@@ -57,6 +57,41 @@ static int model_init_device(cfnerf_model* m) {
         HIPCHK(hipEventCreate(&m->ev1[i]));
     }
     m->ws_bytes = pbytes + sizeof(NetTab);
+    // launch attributes and occupancy belong to (kernel, device): set here, with the model's device current
+    HIPCHK(fused_fwd_set_attributes(cfg->netwidth, cfg->h_alpha_size, &m->fwd_blocks_per_cu));
+    HIPCHK(bwd_set_attributes(cfg->netwidth, cfg->h_alpha_size));
+    return CFNERF_OK;
+}
+
+size_t cfnerf::workspace_bytes_for(const cfnerf_cfg& c, int64_t n, int s, int k) {
+    return Stash::carve(nullptr, nullptr, c, n, s, k, build_layout(c).total);
+}
+
+// Point the stash at its block for an (N,S,K) batch.  A caller-provided block (cfnerf_model_set_workspace) is never
+// grown: too small is an error.  A model-owned block is (re)allocated here - the only place the train path allocates.
+int cfnerf::stash_bind(cfnerf_model* m, int64_t n, int s, int k, char* err, size_t errlen) {
+    Stash& q = m->stash;
+    if (q.base && q.bound_N == n && q.bound_S == s && q.bound_K == k) return CFNERF_OK;
+    const size_t need = Stash::carve(nullptr, nullptr, m->cfg, n, s, k, m->layout.total);
+    if (need > q.cap) {
+        if (q.base && !q.owned) {
+            std::snprintf(err, errlen, "the workspace handed to cfnerf_model_set_workspace holds %zu bytes but N=%lld S=%d K=%d needs %zu "
+                          "(size it with cfnerf_workspace_bytes)", q.cap, (long long)n, s, k, need);
+            return CFNERF_E_NOMEM;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) { std::snprintf(err, errlen, "hipDeviceSynchronize failed"); return CFNERF_E_HIP; }
+        q.release();
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) {
+            std::snprintf(err, errlen, "workspace allocation of %zu bytes failed (N=%lld S=%d K=%d)", need, (long long)n, s, k);
+            return CFNERF_E_NOMEM;
+        }
+        q.base = static_cast<char*>(p); q.cap = need; q.owned = true;
+    }
+    q.used = Stash::carve(&q, q.base, m->cfg, n, s, k, m->layout.total);
+    q.bound_N = n; q.bound_S = s; q.bound_K = k;
+    q.valid = false;
+    ++q.bind_serial;
     return CFNERF_OK;
 }
 
@@ -209,7 +244,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     a.ent_partials = train ? m->d_ent_partials : nullptr;
     if ((flags & CFNERF_F_STASH) && !maps) return fail(CFNERF_E_INVALID, "STASH needs the per-K maps");
     if (flags & CFNERF_F_STASH) {
-        if (int rc = m->stash.ensure(m->cfg, N, S, K)) return fail(rc, "stash allocation failed (%lld points)", (long long)a.P);
+        char why[256];
+        if (int rc = stash_bind(m, N, S, K, why, sizeof why)) return fail(rc, "%s", why);
         Stash& q = m->stash;
         a.st_enc = q.enc; a.st_gd = q.gd; a.st_h = q.h; a.st_feat = q.feat; a.st_v = q.v; a.st_ha = q.ha; a.st_hr = q.hr;
         a.st_theta = q.theta; a.st_z = q.z; a.st_at = q.at;
@@ -217,14 +253,14 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         q.n_tiles = N * (int64_t)((S + kTileM - 1) / kTileM);
         a.n_tiles = q.n_tiles;
         a.raw = q.raw;                       // the backward reads the model's OWN copy: the caller may drop its tensor
-        q.raw_used = q.raw;
         HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
         q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true;
+        ++q.generation;                      // this forward now owns the one stash: older backward passes are refused
     }
     int grid = 0;
     if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
-    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, st, &grid));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
     if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
     if ((flags & CFNERF_F_STASH) && raw_opt)
         HIPCHK(hipMemcpyAsync(raw_opt, m->stash.raw, (size_t)a.P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -258,7 +294,7 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
     int grid = 0;
-    HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->precision, m->n_cu, st, &grid));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out, st));
     return CFNERF_OK;
@@ -287,7 +323,28 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
     return CFNERF_OK;
 }
 
-int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m) { return m ? (int64_t)(m->ws_bytes + m->stash.bytes) : 0; }
+int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m) { return m ? (int64_t)(m->ws_bytes + m->stash.cap) : 0; }
+
+int64_t cfnerf_workspace_bytes(const cfnerf_cfg* cfg, int64_t N, int S, int K) {
+    if (!cfg) { fail(CFNERF_E_INVALID, "cfg is NULL"); return -1; }
+    if (const char* why = validate_cfg(*cfg)) { fail(CFNERF_E_UNSUPPORTED, "%s", why); return -1; }
+    if (N < 0 || S < 1 || K < 1 || K > kMaxK) { fail(CFNERF_E_INVALID, "bad N/S/K"); return -1; }
+    return (int64_t)workspace_bytes_for(*cfg, N, S, K);
+}
+
+int cfnerf_model_set_workspace(cfnerf_model* m, void* workspace, size_t bytes) {
+    if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
+    if ((workspace == nullptr) != (bytes == 0)) return fail(CFNERF_E_INVALID, "workspace and bytes must both be given or both be 0");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(CFNERF_E_INVALID, "workspace must be 256-byte aligned");
+    if (int rc = check_device(m)) return rc;
+    Stash& q = m->stash;
+    if (q.owned && q.base) HIPCHK(hipDeviceSynchronize());      // kernels may still use the block about to be freed
+    q.release();                                                // frees a model-owned block; forgets a caller-owned one
+    if (workspace) { q.base = static_cast<char*>(workspace); q.cap = bytes; q.owned = false; }
+    return CFNERF_OK;
+}
+
+uint64_t cfnerf_model_stash_generation(const cfnerf_model* m) { return (m && m->stash.valid) ? m->stash.generation : 0; }
 
 int cfnerf_timing_enable(cfnerf_model* m, int enable) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");

@@ -54,34 +54,16 @@ struct BwdPlan {
     bool built = false;
     int nb = 0, db_h = 0, db_feat = 0, db_v = 0, db_ha = 0, db_hr = 0, db_theta = 0;
     std::vector<BiasMap> bias_maps;
-    BiasMap* d_bias_maps = nullptr;
-    float* d_dbp = nullptr; int dbp_wg = 0;
-    float* d_zeros = nullptr;                             // 256-B zero page for out-of-range operand fetches
-    float* d_partials = nullptr; int partials_split = 0;
-    DwTile *d_tiles = nullptr, *d_tiles_small = nullptr;
-    DwBlock *d_blocks = nullptr, *d_blocks_small = nullptr;
-    int n_blocks = 0, n_blocks_small = 0;
-    RedSeg* d_segs = nullptr; int n_segs = 0;
-    const float* tiles_for = nullptr; int64_t tiles_P = 0;
+    // host copies of the weight-gradient descriptors; they stay alive while their upload may be in flight
+    std::vector<DwTile> tiles, tiles_small;
+    std::vector<DwBlock> blocks, blocks_small;
+    std::vector<RedSeg> segs;
+    hipEvent_t uploaded = nullptr;                        // recorded after the descriptor uploads of the last rebuild
+    uint64_t bind_serial = ~0ull;                         // Stash::bind_serial the descriptors were built for
+    int ns_big = 0, ns_small = 0;
     void release() {
-        if (d_bias_maps) (void)hipFree(d_bias_maps);
-        if (d_dbp) (void)hipFree(d_dbp);
-        if (d_zeros) (void)hipFree(d_zeros);
-        d_zeros = nullptr;
-        if (d_partials) (void)hipFree(d_partials);
-        release_tiles();
-        d_bias_maps = nullptr; d_dbp = nullptr; d_partials = nullptr;
-        dbp_wg = partials_split = 0;
-    }
-    void release_tiles() {
-        if (d_tiles) (void)hipFree(d_tiles);
-        if (d_tiles_small) (void)hipFree(d_tiles_small);
-        if (d_blocks) (void)hipFree(d_blocks);
-        if (d_blocks_small) (void)hipFree(d_blocks_small);
-        if (d_segs) (void)hipFree(d_segs);
-        d_segs = nullptr; n_segs = 0;
-        d_tiles = d_tiles_small = nullptr; d_blocks = d_blocks_small = nullptr;
-        n_blocks = n_blocks_small = 0; tiles_for = nullptr; tiles_P = 0;
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        uploaded = nullptr; bind_serial = ~0ull;
     }
 };
 

@@ -831,28 +831,41 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // ================================================================================================
 // host side
-static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, int n_cu, hipStream_t st, int* grid_out) {
+static const void* bwd_data_fn(int W, bool b16) {
+    switch (W) {
+        case 64: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_F32>);
+        case 128: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_F32>);
+        case 256: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_F32>);
+        case 512: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_F32>);
+    }
+    return nullptr;
+}
+
+static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, hipStream_t st, int* grid_out) {
     const size_t lds = bwd_lds_bytes(ht.W, ht.ha_sz);
-    const void* fn = nullptr;
-    const bool b16 = prec == PREC_BF16X3;
-    switch (ht.W) {
-        case 64: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_F32>); break;
-        case 128: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_F32>); break;
-        case 256: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_F32>); break;
-        case 512: fn = b16 ? reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_F32>); break;
-        default: return hipErrorInvalidValue;
-    }
-    static size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int wi = (ht.W == 64 ? 0 : ht.W == 128 ? 1 : ht.W == 256 ? 2 : 3) + (b16 ? 4 : 0);
-    if (lds_set[wi] != lds) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set[wi] = lds;
-    }
+    const void* fn = bwd_data_fn(ht.W, prec == PREC_BF16X3);
+    if (!fn) return hipErrorInvalidValue;
     int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)a.n_wg);
     if (grid_out) *grid_out = grid;
     void* args[] = {const_cast<BwdArgs*>(&a)};
     return hipLaunchKernel(fn, dim3(grid), dim3(kThreads), args, lds, st);
+}
+
+constexpr size_t kDwBigLds = 4 * kDwRows * 256 * sizeof(float);
+constexpr size_t kDwSmallLds = 2 * kDwRows * kDsMaxCols * sizeof(float);
+
+// Per-DEVICE set-up of the backward kernels of one width (called from cfnerf_model_create with that device current)
+hipError_t bwd_set_attributes(int W, int ha) {
+    const size_t lds = bwd_lds_bytes(W, ha);
+    for (int b16 = 0; b16 < 2; ++b16) {
+        hipError_t e = hipFuncSetAttribute(bwd_data_fn(W, b16 != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwSmallLds);
 }
 
 }  // namespace cfnerf
@@ -878,13 +891,13 @@ static int bfail(int code, const char* fmt, ...) {
     } while (0)
 
 // build (once per model) the weight-gradient tile list, the bias map and their device copies
-static int ensure_bwd_plan(cfnerf_model* m) {
+int cfnerf::ensure_bwd_plan(cfnerf_model* m) {
     BwdPlan& B = m->bwd;
     if (B.built) return 0;
     const cfnerf_cfg& c = m->cfg;
     const ParamLayout& L = m->layout;
     const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
-    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = skip_layer(D);
     // bias partial table columns
     int nb = 0;
     B.db_h = nb; nb += D * W;
@@ -946,7 +959,7 @@ static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
 static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash& q, int64_t P, std::vector<DwTile>& big,
                           std::vector<DwTile>& small) {
     const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
-    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = skip_layer(D);
     char key[64];
     const int one_row[1] = {0};
     for (int l = 0; l < D; ++l) {
@@ -986,17 +999,21 @@ static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
 }
 
 // per_kslice: one block per existing 64-wide k-slice of every tile (small kernel), else one block per tile
-static void make_blocks(std::vector<DwBlock>& blocks, const std::vector<DwTile>& tiles, int nsplit, int64_t P, int round_to, bool per_kslice) {
+// returns the number of non-empty splits: exactly the slots [0, that) of every tile's tensor are written by a launch
+static int make_blocks(std::vector<DwBlock>& blocks, const std::vector<DwTile>& tiles, int nsplit, int64_t P, int round_to, bool per_kslice) {
     int64_t chunk = (P + nsplit - 1) / nsplit;
     chunk = (chunk + round_to - 1) / round_to * round_to;
+    int used = 0;
     for (int s = 0; s < nsplit; ++s) {
         const int64_t pb = (int64_t)s * chunk, pe = std::min<int64_t>(P, pb + chunk);
         if (pb >= pe) continue;
+        ++used;
         for (int t = 0; t < (int)tiles.size(); ++t) {
             const int nks = per_kslice ? std::min(4, (tiles[t].K - tiles[t].k0 + 63) / 64) : 1;
             for (int ks = 0; ks < nks; ++ks) { DwBlock b; b.tile = t; b.split = s; b.kslice = ks; b.pb = pb; b.pe = pe; blocks.push_back(b); }
         }
     }
+    return used;
 }
 
 extern "C" {
@@ -1012,100 +1029,72 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
     return CFNERF_OK;
 }
 
-int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_depth_map, const float* d_entropy,
-                      float* grad_flat, cfnerf_stream s) {
+int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+                      const float* d_entropy, float* grad_flat, cfnerf_stream s) {
     if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
     Stash& q = m->stash;
     if (!q.valid) return bfail(CFNERF_E_INVALID, "no stashed forward: call cfnerf_render_fwd with CFNERF_F_STASH first");
+    if (stash_generation != q.generation)
+        return bfail(CFNERF_E_INVALID, "stale stash: this backward belongs to STASH forward #%llu but the model's one stash now holds "
+                     "forward #%llu (a later grad-enabled forward overwrote it; run each backward before the next STASH forward)",
+                     (unsigned long long)stash_generation, (unsigned long long)q.generation);
     if (q.S > 4096) return bfail(CFNERF_E_UNSUPPORTED, "backward supports S <= 4096");
     hipStream_t st = (hipStream_t)s;
     if (int rc = ensure_bwd_plan(m)) return rc;
     BwdPlan& B = m->bwd;
     const cfnerf_cfg& c = m->cfg;
-    const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
-    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = D / 2;
+    const int W = c.netwidth;
     const int64_t N = q.N, P = q.N * (int64_t)q.S, n_params = m->layout.total;
     const ParamLayout& L = m->layout;
+    const int n_wg = std::min(m->n_cu, kMaxCu) * ((W <= 256) ? 2 : 1);
 
-    // ---- workspace sizes that depend on the batch
-    const int n_wg = m->n_cu * ((W <= 256) ? 2 : 1);
-    const int kMaxSplit = 64, kSlots = 128;      // split slots: big tiles use <= kMaxSplit, small jobs up to kSlots
-    if (B.dbp_wg < n_wg || !B.d_dbp) {
-        if (B.d_dbp) hipFree(B.d_dbp);
-        BHIP(hipMalloc(&B.d_dbp, (size_t)n_wg * B.nb * sizeof(float)));
-        B.dbp_wg = n_wg;
-    }
-    if (!B.d_partials) {
-        BHIP(hipMalloc(&B.d_partials, (size_t)kSlots * n_params * sizeof(float)));
-        B.partials_split = kSlots;
-    }
-    if (!B.d_zeros) {
-        BHIP(hipMalloc(&B.d_zeros, 256));
-        BHIP(hipMemsetAsync(B.d_zeros, 0, 256, st));
-    }
-    if (!B.d_bias_maps) {
-        BHIP(hipMalloc(&B.d_bias_maps, B.bias_maps.size() * sizeof(BiasMap)));
-        BHIP(hipMemcpyAsync(B.d_bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap), hipMemcpyHostToDevice, st));
-    }
-    // ---- weight-gradient tile list (pointers depend on the stash allocation)
-    if (B.tiles_for != q.h || B.tiles_P != P) {
-        std::vector<DwTile> big, small;
-        build_dw_jobs(c, L, q, P, big, small);
+    // ---- weight-gradient descriptors: they hold workspace pointers, so they are rebuilt (and uploaded, asynchronously,
+    //      from host vectors that outlive the copy) only when the workspace binding moved - never on the steady path
+    if (B.bind_serial != q.bind_serial) {
+        if (B.uploaded) BHIP(hipEventSynchronize(B.uploaded));       // the previous upload no longer reads the host vectors
+        else BHIP(hipEventCreateWithFlags(&B.uploaded, hipEventDisableTiming));
+        B.tiles.clear(); B.tiles_small.clear(); B.blocks.clear(); B.blocks_small.clear(); B.segs.clear();
+        build_dw_jobs(c, L, q, P, B.tiles, B.tiles_small);
         // split counts: every block of a kernel gets the same number of points; big tiles ~1 block per CU in total,
         // small jobs a finer split (their blocks are short and run several per CU)
-        int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, big.size())));
+        const int kMaxSplit = 64;
+        int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, B.tiles.size())));
         ns_big = std::min(ns_big, kMaxSplit);
         while (ns_big > 1 && P / ns_big < 512) --ns_big;
-        int ns_small = kSlots;
+        int ns_small = kDwSlots;
         while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
-        std::vector<DwBlock> bb, sb;
-        make_blocks(bb, big, ns_big, P, kDwRows, false);
-        make_blocks(sb, small, ns_small, P, kDwRows, false);
-        B.release_tiles();
-        BHIP(hipMalloc(&B.d_tiles, std::max<size_t>(1, big.size()) * sizeof(DwTile)));
-        BHIP(hipMalloc(&B.d_tiles_small, std::max<size_t>(1, small.size()) * sizeof(DwTile)));
-        BHIP(hipMalloc(&B.d_blocks, std::max<size_t>(1, bb.size()) * sizeof(DwBlock)));
-        BHIP(hipMalloc(&B.d_blocks_small, std::max<size_t>(1, sb.size()) * sizeof(DwBlock)));
-        BHIP(hipMemcpyAsync(B.d_tiles, big.data(), big.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
-        BHIP(hipMemcpyAsync(B.d_tiles_small, small.data(), small.size() * sizeof(DwTile), hipMemcpyHostToDevice, st));
-        BHIP(hipMemcpyAsync(B.d_blocks, bb.data(), bb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
-        BHIP(hipMemcpyAsync(B.d_blocks_small, sb.data(), sb.size() * sizeof(DwBlock), hipMemcpyHostToDevice, st));
-        // split slots a tile does not write must read as zero in the reduction
-        BHIP(hipMemsetAsync(B.d_partials, 0, (size_t)kSlots * n_params * sizeof(float), st));
-        BHIP(hipStreamSynchronize(st));       // the vectors are host temporaries
-        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots)
-        {
-            std::vector<RedSeg> segs;
-            for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; segs.push_back(r); }
-            auto mark = [&](const std::vector<DwTile>& tv, int ns) {
-                for (const DwTile& t : tv)
-                    for (int q = 0; q < t.nseg; ++q)
-                        for (RedSeg& r : segs)
-                            if (r.begin == t.seg_dst[q]) r.nsplit = std::max(r.nsplit, ns);
-            };
-            mark(big, ns_big); mark(small, ns_small);
-            if (B.d_segs) (void)hipFree(B.d_segs);
-            BHIP(hipMalloc(&B.d_segs, segs.size() * sizeof(RedSeg)));
-            BHIP(hipMemcpyAsync(B.d_segs, segs.data(), segs.size() * sizeof(RedSeg), hipMemcpyHostToDevice, st));
-            B.n_segs = (int)segs.size();
-        }
-        B.n_blocks = (int)bb.size(); B.n_blocks_small = (int)sb.size();
-        B.tiles_for = q.h; B.tiles_P = P;
-        static bool attr_set = false;
-        if (!attr_set) {
-            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(4 * kDwRows * 256 * sizeof(float))));
-            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(4 * kDwRows * 256 * sizeof(float))));
-            BHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(2 * kDwRows * kDsMaxCols * sizeof(float))));
-            attr_set = true;
-        }
+        B.ns_big = make_blocks(B.blocks, B.tiles, ns_big, P, kDwRows, false);
+        B.ns_small = make_blocks(B.blocks_small, B.tiles_small, ns_small, P, kDwRows, false);
+        if ((int)B.tiles.size() > kMaxDwTiles || (int)B.tiles_small.size() > kMaxDwTiles || (int)B.blocks.size() > kMaxDwBlocks ||
+            (int)B.blocks_small.size() > kMaxDwBlocks)
+            return bfail(CFNERF_E_UNSUPPORTED, "weight-gradient plan exceeds the descriptor capacity (%zu/%zu tiles, %zu/%zu blocks)",
+                         B.tiles.size(), B.tiles_small.size(), B.blocks.size(), B.blocks_small.size());
+        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  A launch writes every slot below
+        // its tensor's count, so the partial buffer never needs clearing.
+        for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; B.segs.push_back(r); }
+        auto mark = [&](const std::vector<DwTile>& tv, int ns) {
+            for (const DwTile& t : tv)
+                for (int g = 0; g < t.nseg; ++g)
+                    for (RedSeg& r : B.segs)
+                        if (r.begin == t.seg_dst[g]) r.nsplit = std::max(r.nsplit, ns);
+        };
+        mark(B.tiles, B.ns_big); mark(B.tiles_small, B.ns_small);
+        if (B.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
+        auto up = [&](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+        BHIP(up(q.tiles, B.tiles.data(), B.tiles.size() * sizeof(DwTile)));
+        BHIP(up(q.tiles_small, B.tiles_small.data(), B.tiles_small.size() * sizeof(DwTile)));
+        BHIP(up(q.blocks, B.blocks.data(), B.blocks.size() * sizeof(DwBlock)));
+        BHIP(up(q.blocks_small, B.blocks_small.data(), B.blocks_small.size() * sizeof(DwBlock)));
+        BHIP(up(q.segs, B.segs.data(), B.segs.size() * sizeof(RedSeg)));
+        BHIP(up(q.bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap)));
+        BHIP(hipMemsetAsync(q.zeros, 0, 256, st));
+        BHIP(hipEventRecord(B.uploaded, st));
+        B.bind_serial = q.bind_serial;
     }
 
     // ---- 1. tail
     TailArgs ta{};
-    ta.raw = q.raw_used; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
+    ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
     ta.d_rgb = d_rgb_map; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
     ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
     if (m->timing) BHIP(hipEventRecord(m->ev0[1], st));
@@ -1114,38 +1103,38 @@ int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_de
     if (m->timing) BHIP(hipEventRecord(m->ev1[1], st));
 
     // ---- 2. fused backward-data (+ bias partials)
-    BHIP(hipMemsetAsync(B.d_dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
+    BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
     BwdArgs ba{};
     ba.tab = m->d_tab; ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
-    ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = B.d_dbp;
+    ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
     if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));
-    BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, m->n_cu, st, &grid_bd));
+    BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, st, &grid_bd));
     if (m->timing) BHIP(hipEventRecord(m->ev1[2], st));
 
     // ---- 3. weight gradients + reductions
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
-    if (B.n_blocks > 0) {
+    if (!B.blocks.empty()) {
         if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
-                               B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
+            hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)B.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
+                               q.tiles, q.blocks, q.partials, n_params, q.zeros);
         else
-            hipLaunchKernelGGL(dw_big_kernel<PREC_F32>, dim3((unsigned)B.n_blocks), dim3(kDwThreads), 4 * kDwRows * 256 * sizeof(float), st,
-                               B.d_tiles, B.d_blocks, B.d_partials, n_params, B.d_zeros);
+            hipLaunchKernelGGL(dw_big_kernel<PREC_F32>, dim3((unsigned)B.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
+                               q.tiles, q.blocks, q.partials, n_params, q.zeros);
         BHIP(hipGetLastError());
     }
-    if (B.n_blocks_small > 0) {
-        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.n_blocks_small), dim3(kDsThreads), 2 * kDwRows * kDsMaxCols * sizeof(float), st,
-                           B.d_tiles_small, B.d_blocks_small, B.d_partials, n_params, B.d_zeros);
+    if (!B.blocks_small.empty()) {
+        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
+                           q.tiles_small, q.blocks_small, q.partials, n_params, q.zeros);
         BHIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, B.d_partials, B.d_segs, B.n_segs,
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, q.partials, q.segs, (int)B.segs.size(),
                        n_params, grad_flat);
     BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, B.d_dbp, grid_bd, B.nb,
-                       B.d_bias_maps, (int)B.bias_maps.size(), grad_flat);
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
+                       q.bias_maps, (int)B.bias_maps.size(), grad_flat);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N, m->flat, d_entropy, grad_flat);
     BHIP(hipGetLastError());
@@ -1184,7 +1173,7 @@ extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
     std::vector<DwTile> big, small;
     build_dw_jobs(*cfg, L, q, P, big, small);
-    for (float** pp : ptrs) *pp = nullptr;     // nothing was allocated: keep ~Stash / release() from freeing the fakes
+    for (float** pp : ptrs) *pp = nullptr;
     int n = 0;
     for (int pass = 0; pass < 2; ++pass)
         for (const DwTile& t : (pass == 0 ? big : small)) {

@@ -741,21 +741,9 @@ static int max_blocks_per_cu(const void* fn, size_t lds) {
 }
 
 template <int W, int MODE, bool TRAIN, int PREC>
-static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hipStream_t st, int* grid_out) {
+static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
     auto fn = fused_fwd_kernel<W, MODE, TRAIN, PREC>;
     const size_t lds = fwd_lds_bytes(W, ht.ha_sz);
-    static size_t lds_set = 0;
-    static int per_cu = 0;
-    if (lds_set != lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        per_cu = max_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
-#ifdef CFN_FWD_MAX_PER_CU
-        if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
-#endif
-        if (per_cu > 2) per_cu = 2;
-        lds_set = lds;
-    }
     const int64_t units = (MODE == 0) ? a.N : (a.P + kTileM - 1) / kTileM;
     int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
     if (grid < 1) grid = 1;
@@ -765,21 +753,54 @@ static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, hip
 }
 
 template <int W>
-static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out) {
+static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
     if (prec == PREC_BF16X3) {
-        if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_BF16X3>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_BF16X3>(a, ht, n_cu, st, grid_out);
-        return train ? launch_fwd_t<W, 1, true, PREC_BF16X3>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_BF16X3>(a, ht, n_cu, st, grid_out);
+        if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out);
+        return train ? launch_fwd_t<W, 1, true, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out);
     }
-    if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_F32>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_F32>(a, ht, n_cu, st, grid_out);
-    return train ? launch_fwd_t<W, 1, true, PREC_F32>(a, ht, n_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_F32>(a, ht, n_cu, st, grid_out);
+    if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out);
+    return train ? launch_fwd_t<W, 1, true, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out);
 }
 
-hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out) {
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
     switch (ht.W) {
-        case 64: return launch_fwd_w<64>(a, ht, mode, train, prec, n_cu, st, grid_out);
-        case 128: return launch_fwd_w<128>(a, ht, mode, train, prec, n_cu, st, grid_out);
-        case 256: return launch_fwd_w<256>(a, ht, mode, train, prec, n_cu, st, grid_out);
-        case 512: return launch_fwd_w<512>(a, ht, mode, train, prec, n_cu, st, grid_out);
+        case 64: return launch_fwd_w<64>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+        case 128: return launch_fwd_w<128>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+        case 256: return launch_fwd_w<256>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+        case 512: return launch_fwd_w<512>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Per-DEVICE set-up of the fused forward kernels of one width (called from cfnerf_model_create with that device
+// current): raise the dynamic-LDS limit of every variant and read the occupancy.  Nothing here is process-global.
+template <int W>
+static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
+    const size_t lds = fwd_lds_bytes(W, ha);
+    const void* fns[8] = {
+        reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_F32>),
+        reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, true, PREC_F32>),
+        reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, false, PREC_BF16X3>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_BF16X3>),
+        reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, false, PREC_BF16X3>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, true, PREC_BF16X3>)};
+    int per_cu = 2;
+    for (const void* fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        per_cu = std::min(per_cu, max_blocks_per_cu(fn, lds));
+    }
+#ifdef CFN_FWD_MAX_PER_CU
+    if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
+#endif
+    *per_cu_out = std::max(1, per_cu);
+    return hipSuccess;
+}
+
+hipError_t fused_fwd_set_attributes(int W, int ha, int* per_cu_out) {
+    switch (W) {
+        case 64: return fwd_attrs_w<64>(ha, per_cu_out);
+        case 128: return fwd_attrs_w<128>(ha, per_cu_out);
+        case 256: return fwd_attrs_w<256>(ha, per_cu_out);
+        case 512: return fwd_attrs_w<512>(ha, per_cu_out);
     }
     return hipErrorInvalidValue;
 }

@@ -35,7 +35,8 @@ struct FwdArgs {
     int64_t n_tiles;                     // tiles of the launch (rays * chunks per ray)
 };
 
-hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int prec, int n_cu, hipStream_t st, int* grid_out);
+hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int prec, int n_cu, int per_cu, hipStream_t st, int* grid_out);
+hipError_t fused_fwd_set_attributes(int W, int ha, int* per_cu_out);      // per device, at model creation
 int fused_fwd_max_grid(int W, int ha, int n_cu);
 hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
                                    double count, float* out, hipStream_t st);

@@ -35,11 +35,15 @@ struct ParamLayout {
 };
 
 inline int enc_ch(int multires) { return 3 + 6 * multires; }
+// Index i of the reference's `i in self.skips` tests (MOD:39,171) with args.skips = [netdepth / 2] (RUN:327, a FLOAT
+// division): for an odd netdepth the list holds x.5, nothing ever matches and the trunk is a plain MLP with no skip
+// concat.  -2 never equals a layer index (nor index - 1).
+inline int skip_layer(int netdepth) { return (netdepth % 2 == 0) ? netdepth / 2 : -2; }
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // returns nullptr when valid, else the reason
 inline const char* validate_cfg(const cfnerf_cfg& c) {
-    if (c.netdepth < 3 || c.netdepth > kMaxDepth) return "netdepth must be in [3,16] (the skip concat after layer netdepth/2 must feed a trunk layer)";
+    if (c.netdepth < 3 || c.netdepth > kMaxDepth) return "netdepth must be in [3,16] (at netdepth 2 the reference's skip concat feeds feature_linear and crashes)";
     if (c.netwidth != 64 && c.netwidth != 128 && c.netwidth != 256 && c.netwidth != 512)
         return "netwidth must be 64, 128, 256 or 512";
     if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";
@@ -53,7 +57,7 @@ inline const char* validate_cfg(const cfnerf_cfg& c) {
 inline ParamLayout build_layout(const cfnerf_cfg& c) {
     ParamLayout L;
     const int W = c.netwidth, D = c.netdepth, ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), F = c.n_flows;
-    const int skip = D / 2;           // RUN:327 args.skips = [netdepth / 2]
+    const int skip = skip_layer(D);   // RUN:327 args.skips = [netdepth / 2]
     auto add = [&](const std::string& k, int64_t r, int64_t cc) {
         ParamEntry p{k, L.total, r, cc};
         L.total += p.numel();
@@ -107,6 +111,13 @@ struct SubL {
 //   alpha: 96 + [0,F) diag1 | [F,2F) diag2 | [2F,3F) b         (amor_d of z=1 is fully masked: MOD:327,374)
 constexpr int kThetaRgb = 96;
 constexpr int kThetaAll = 128;
+
+constexpr int kMaxCu = 256;           // gfx950 has 256 CUs; per-workgroup partial tables are carved for 2 * kMaxCu workgroups
+// columns of the per-workgroup bias-gradient partial table, and the number of bias tensors it scatters into
+inline int bias_partial_cols(const cfnerf_cfg& c) {
+    return c.netdepth * c.netwidth + c.netwidth + c.netwidth / 2 + pad_to(c.h_alpha_size, 32) + pad_to(c.h_rgb_size, 32) + kThetaAll;
+}
+inline int bias_map_count(const cfnerf_cfg& c) { return c.netdepth + 4 + 7; }
 
 struct NetTab {
     // forward
@@ -185,7 +196,7 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
     NetTab& T = P.tab;
     std::memset(&T, 0, sizeof(T));
     const int W = c.netwidth, D = c.netdepth, ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), F = c.n_flows;
-    T.D = D; T.W = W; T.skip = D / 2; T.ic = ic; T.icv = icv; T.ha_sz = c.h_alpha_size; T.hr_sz = c.h_rgb_size; T.F = F;
+    T.D = D; T.W = W; T.skip = skip_layer(D); T.ic = ic; T.icv = icv; T.ha_sz = c.h_alpha_size; T.hr_sz = c.h_rgb_size; T.F = F;
     uint32_t cur = 0, cur16 = 0;
     auto alloc_op = [&](int n_out, int k_red, bool bias) {
         SubL s;

@@ -1,7 +1,8 @@
-// cfnerf_model.h - the opaque cfnerf_model handle: packed weights, operand table, activation stash.
+// cfnerf_model.h - the opaque cfnerf_model handle: packed weights, operand table, train-step workspace.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "cfnerf_layout.h"
@@ -10,10 +11,16 @@
 namespace cfnerf {
 
 constexpr int kNumTimers = 5;   // 0 fwd, 1 bwd_tail, 2 bwd_data, 3 bwd_dw, 4 adam
+constexpr int kDwSlots = 128;   // split-K slots of the weight-gradient partials (upper bound of any split count)
+constexpr int kMaxDwTiles = 256, kMaxDwBlocks = 16384;     // descriptor capacities carved out of the workspace
 
-// Activations kept by a CFNERF_F_STASH forward for cfnerf_render_bwd.  Row-major per point.
-// Sized for 288 GB of HBM: ~11 KB per point at W = 256 (1.4 GB for a 1024-ray x 128-sample batch).
+// Everything a CFNERF_F_STASH forward keeps for cfnerf_render_bwd plus every buffer the backward writes, carved out of
+// ONE block of device memory: either handed in by the caller (cfnerf_model_set_workspace, sized with
+// cfnerf_workspace_bytes) or - when the caller gave none - owned by the model and grown on demand.
+// Activations are row-major per point.  ~10.6 KB per point at W = 256 (1.4 GB for 1024 rays x 128 samples), the
+// same again for the pre-activation gradients: sized for 288 GB of HBM.
 struct Stash {
+    // ---- written by the forward
     float *enc = nullptr;    // [P,64]   gamma(p) (padded)
     float *gd = nullptr;     // [P,32]   gamma(d) (padded)
     float *h = nullptr;      // [D,P,W]  trunk activations (post-ReLU)
@@ -23,54 +30,75 @@ struct Stash {
     float *hr = nullptr;     // [P,HR]
     float *theta = nullptr;  // [P,128]  flow parameters (diagonals tanh-ed)
     float *z = nullptr;      // [P]      z_vals
-    float *raw = nullptr;    // [P,K,4]  (used when the caller did not ask for raw)
+    float *raw = nullptr;    // [P,K,4]
     float *rays = nullptr;   // [N,11]
-    float *at = nullptr;     // [P,K,2] alpha, T
-    float *dbp = nullptr;    // [n_wg, NB] per-workgroup bias-gradient partials
-    float *gms = nullptr;    // [n_waves, 8] base-Gaussian gradient partials
+    float *at = nullptr;     // [P,K,2]  alpha, T
     float *mbits = nullptr;  // [D+1][tiles][W/32][64] u32 ReLU mask words (fragment order)
-    int64_t n_tiles = 0;
-    // backward workspaces (same row-major-per-point convention)
+    // ---- written by the backward (same row-major-per-point convention)
+    float *gms = nullptr;       // [N,8]    base-Gaussian gradient partials
     float *g_theta = nullptr;   // [P,128]  d loss / d theta (pre-tanh for the diagonal columns)
     float *g_hr = nullptr;      // [P,HR]
     float *g_ha = nullptr;      // [P,HA]
     float *g_v = nullptr;       // [P,W/2]  pre-activation gradient of the views layer
     float *g_feat = nullptr;    // [P,W]
     float *g_h = nullptr;       // [D,P,W]  pre-activation gradients of the trunk layers
-    const float* raw_used = nullptr;
-    int64_t cap_P = 0, cap_N = 0; int cap_K = 0;
-    int64_t N = 0; int S = 0, K = 0, flags = 0;
-    bool valid = false;
-    size_t bytes = 0;
+    float *dbp = nullptr;       // [n_wg, nb] per-workgroup bias-gradient partials
+    float *partials = nullptr;  // [kDwSlots, n_params] split-K weight-gradient partials
+    float *zeros = nullptr;     // 256-B zero page for out-of-range operand fetches
+    BiasMap* bias_maps = nullptr;
+    DwTile *tiles = nullptr, *tiles_small = nullptr;
+    DwBlock *blocks = nullptr, *blocks_small = nullptr;
+    RedSeg* segs = nullptr;
 
-    void release() {
-        float** all[] = {&enc, &gd, &h, &feat, &v, &ha, &hr, &theta, &z, &raw, &rays, &at, &dbp, &gms, &mbits,
-                         &g_theta, &g_hr, &g_ha, &g_v, &g_feat, &g_h};
-        for (float** p : all) { if (*p) hipFree(*p); *p = nullptr; }
-        cap_P = cap_N = 0; cap_K = 0; bytes = 0; valid = false;
+    int64_t n_tiles = 0;
+    int64_t N = 0; int S = 0, K = 0, flags = 0;
+    bool valid = false;             // a STASH forward has filled it
+    uint64_t generation = 0;        // bumped by every STASH forward; cfnerf_render_bwd checks the caller's copy against it
+
+    // binding
+    char* base = nullptr; size_t cap = 0; bool owned = false;
+    int64_t bound_N = -1; int bound_S = 0, bound_K = 0;
+    uint64_t bind_serial = 0;       // bumped whenever the pointers above move (the weight-gradient tile list depends on them)
+    size_t used = 0;
+
+    // Lay the buffers out from `b` (nullptr: only measure).  Returns the bytes needed.  256-B aligned pieces.
+    static size_t carve(Stash* q, char* b, const cfnerf_cfg& c, int64_t n, int s, int k, int64_t n_params) {
+        const int W = c.netwidth, D = c.netdepth;
+        const int64_t P = n * (int64_t)s;
+        const int64_t tiles = n * (int64_t)((s + kTileM - 1) / kTileM);
+        const int n_wg = kMaxCu * ((W <= 256) ? 2 : 1);
+        const int nb = bias_partial_cols(c), n_bias_maps = bias_map_count(c);
+        size_t off = 0;
+        auto take = [&](auto** p, size_t count, size_t elem) {
+            if (q) *p = reinterpret_cast<std::remove_reference_t<decltype(**p)>*>(b + off);
+            off += (count * elem + 255) / 256 * 256;
+        };
+        Stash dummy;
+        Stash* t = q ? q : &dummy;
+        take(&t->enc, (size_t)P * 64, 4); take(&t->gd, (size_t)P * 32, 4);
+        take(&t->h, (size_t)D * P * W, 4); take(&t->feat, (size_t)P * W, 4); take(&t->v, (size_t)P * (W / 2), 4);
+        take(&t->ha, (size_t)P * c.h_alpha_size, 4); take(&t->hr, (size_t)P * c.h_rgb_size, 4);
+        take(&t->theta, (size_t)P * kThetaAll, 4); take(&t->z, (size_t)P + 1, 4); take(&t->raw, (size_t)P * k * 4, 4);
+        take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
+        take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
+        take(&t->gms, (size_t)(n + 8) * 8, 4);
+        take(&t->g_theta, (size_t)P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);
+        take(&t->g_ha, (size_t)P * c.h_alpha_size, 4); take(&t->g_v, (size_t)P * (W / 2), 4);
+        take(&t->g_feat, (size_t)P * W, 4); take(&t->g_h, (size_t)D * P * W, 4);
+        take(&t->dbp, (size_t)n_wg * nb, 4);
+        take(&t->partials, (size_t)kDwSlots * n_params, 4);
+        take(&t->zeros, 64, 4);
+        take(&t->bias_maps, (size_t)n_bias_maps, sizeof(BiasMap));
+        take(&t->tiles, kMaxDwTiles, sizeof(DwTile)); take(&t->tiles_small, kMaxDwTiles, sizeof(DwTile));
+        take(&t->blocks, kMaxDwBlocks, sizeof(DwBlock)); take(&t->blocks_small, kMaxDwBlocks, sizeof(DwBlock));
+        take(&t->segs, 256, sizeof(RedSeg));
+        return off;
     }
 
-    int ensure(const cfnerf_cfg& c, int64_t n, int s, int k) {
-        const int64_t P = n * (int64_t)s;
-        if (P <= cap_P && n <= cap_N && k <= cap_K) return 0;
-        hipDeviceSynchronize();
-        release();
-        const int W = c.netwidth, D = c.netdepth;
-        size_t total = 0;
-        auto al = [&](float** p, size_t nfloat) {
-            if (hipMalloc(p, nfloat * sizeof(float)) != hipSuccess) return false;
-            total += nfloat * sizeof(float);
-            return true;
-        };
-        bool ok = al(&enc, (size_t)P * 64) && al(&gd, (size_t)P * 32) && al(&h, (size_t)D * P * W) && al(&feat, (size_t)P * W) &&
-                  al(&v, (size_t)P * (W / 2)) && al(&ha, (size_t)P * c.h_alpha_size) && al(&hr, (size_t)P * c.h_rgb_size) &&
-                  al(&theta, (size_t)P * kThetaAll) && al(&z, (size_t)P) && al(&raw, (size_t)P * k * 4) &&
-                  al(&rays, (size_t)n * 11) && al(&at, (size_t)P * k * 2) && al(&gms, (size_t)(n + 8) * 8) && al(&mbits, (size_t)(D + 1) * (n * ((s + 63) / 64)) * (W / 32) * 64) && al(&g_theta, (size_t)P * kThetaAll) && al(&g_hr, (size_t)P * c.h_rgb_size) &&
-                  al(&g_ha, (size_t)P * c.h_alpha_size) && al(&g_v, (size_t)P * (W / 2)) && al(&g_feat, (size_t)P * W) &&
-                  al(&g_h, (size_t)D * P * W);
-        if (!ok) { release(); return CFNERF_E_NOMEM; }
-        cap_P = P; cap_N = n; cap_K = k; bytes = total;
-        return 0;
+    void release() {
+        if (owned && base) (void)hipFree(base);
+        base = nullptr; cap = 0; owned = false; valid = false; bound_N = -1; used = 0;
+        ++bind_serial;
     }
 };
 
@@ -91,7 +119,16 @@ struct cfnerf_model {
     float* d_eps = nullptr;               // eps of the stashed forward
     cfnerf::Stash stash;
     cfnerf::BwdPlan bwd;
+    int fwd_blocks_per_cu = 1;            // occupancy of the fused forward on THIS device (set at create)
     bool timing = false;
     hipEvent_t ev0[cfnerf::kNumTimers]{}, ev1[cfnerf::kNumTimers]{};
     size_t ws_bytes = 0;
 };
+
+namespace cfnerf {
+// (re)bind the stash pointers for an (N,S,K) batch; grows a model-owned block, rejects a caller block that is too small
+int stash_bind(cfnerf_model* m, int64_t n, int s, int k, char* err, size_t errlen);
+int ensure_bwd_plan(cfnerf_model* m);
+size_t workspace_bytes_for(const cfnerf_cfg& c, int64_t n, int s, int k);
+hipError_t bwd_set_attributes(int W, int ha);             // dynamic-LDS limits of the backward kernels, per device
+}  // namespace cfnerf

@@ -42,23 +42,47 @@ def lr_at(lrate: float, lrate_decay: int, start: int, t: int) -> float:
 
 
 def allreduce_sum_(grad: torch.Tensor, world: int, group=None, force: bool = False):
+    """ONE sum all-reduce of the flat buffer (RCCL over xGMI when the group's backend is "nccl").  A gloo group (CPU
+    tests, two test processes sharing one GPU) is served through a host staging copy."""
     if world > 1 or force:
         import torch.distributed as dist
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+        if grad.is_cuda and dist.get_backend(group) == "gloo":
+            host = grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            grad.copy_(host)
+        else:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
 
 
+MAX_K = 64      # kMaxK of the kernels
+
+
 class Trainer:
+    """Fused train step on one rank.  Multi-GPU: construct with ``world_size`` (and ``group``) after
+    ``torch.distributed.init_process_group``; every rank renders its own shard of the step's rays.
+
+    Latent samples: the reference draws eps once per forward call (MOD:234,246); here every rank must use the SAME eps in
+    a step.  That is enforced, not assumed: rank 0 draws the latents of step t+1 and they travel in a 4*K-float tail of
+    the step-t gradient all-reduce (the other ranks contribute zeros there), so no extra collective and no reliance on
+    identical seeding; step 0 uses one broadcast.  An explicit ``eps=`` argument overrides this (tests, benchmarks)."""
+
     def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False):
         self.force_allreduce = bool(force_allreduce)
         self.net: NeRF_Flows = _unwrap(net)
         dev = self.net.flat.device
         self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
         self.world, self.group, self.start = int(world_size), group, int(start)
+        self.rank = 0
+        if self.world > 1 or self.force_allreduce:
+            import torch.distributed as dist
+            self.rank = dist.get_rank(group)
         n = self.net.n_params
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
-        self.grad = torch.zeros(n, device=dev)
+        self.gbuf = torch.zeros(n + 4 * MAX_K, device=dev)      # flat gradient | next step's latents (rank 0's, via the all-reduce)
+        self.grad = self.gbuf[:n]
+        self._eps_next = None
         self.d_ent = torch.tensor([self.beta1 / self.world], device=dev)
         # loss, loss_nll, mse, psnr of the local shard; loss and loss_nll are CONTRIBUTIONS (nll / (3 N_total) and
         # beta1 / world on the shard's entropy): their sum over ranks is the global value (RUN:1042-1050)
@@ -66,6 +90,36 @@ class Trainer:
         self.entropy = torch.zeros(1, device=dev)
         self.t = 0
         self._buf_n = None
+
+    def _step_eps(self):
+        """Latents of the coming step, identical on every rank."""
+        net = self.net
+        if self.world == 1 and not self.force_allreduce:
+            return net.draw_eps()
+        if self._eps_next is None:                              # first step: one broadcast from rank 0
+            import torch.distributed as dist
+            eps = net.draw_eps() if self.rank == 0 else torch.zeros(net.K_samples, 4, device=net.flat.device)
+            if eps.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = eps.cpu()
+                dist.broadcast(host, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                eps = host.to(eps.device)
+            else:
+                dist.broadcast(eps, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            return eps
+        return self._eps_next
+
+    def _queue_next_eps(self):
+        """Before the all-reduce: rank 0 writes the NEXT step's latents behind the gradient, everyone else zeros."""
+        K, n = self.net.K_samples, self.net.n_params
+        tail = self.gbuf[n:n + 4 * K]
+        if self.rank == 0:
+            tail.copy_(self.net.draw_eps().reshape(-1))
+        else:
+            tail.zero_()
+
+    def _take_next_eps(self):
+        K, n = self.net.K_samples, self.net.n_params
+        self._eps_next = self.gbuf[n:n + 4 * K].reshape(K, 4).clone()
 
     def _buffers(self, N, K):
         if self._buf_n != (N, K):
@@ -103,6 +157,7 @@ class Trainer:
             eps = net.draw_eps()
         eps = _f32c(eps)
         net._sync()
+        net.ensure_workspace(N, S, K)
         flags = L.F_STASH | L.F_TRAIN | (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0)
         L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(_f32c(t_rand) if t_rand is not None else None),
                                       None, L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
@@ -110,15 +165,22 @@ class Trainer:
         L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
                                         C.c_float(self.beta1 / self.world), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
                 "cfnerf_loss_fwd_bwd")
-        L.check(lib.cfnerf_render_bwd(net.handle, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
+        gen = lib.cfnerf_model_stash_generation(net.handle)
+        L.check(lib.cfnerf_render_bwd(net.handle, gen, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
                                       L.ptr(self.grad), st), "cfnerf_render_bwd")
         return self.grad
 
     def step(self, H, W, focal, rays, target, **kw):
         """One full train step.  Returns the device tensor [loss, loss_nll, mse, psnr] of the local shard."""
         kw = {k: v for k, v in kw.items() if k in ("t_rand", "eps", "near", "far", "ndc", "lindisp", "white_bkgd", "perturb", "t_vals")}
+        dist_on = self.world > 1 or self.force_allreduce
+        if kw.get("eps") is None and dist_on:
+            kw["eps"] = self._step_eps()
         self.forward_backward(H, W, focal, rays, target, **kw)
-        allreduce_sum_(self.grad, self.world, self.group, self.force_allreduce)
+        if dist_on:
+            self._queue_next_eps()
+            allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
+            self._take_next_eps()
         lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
         self.t += 1
         net = self.net

@@ -10,10 +10,13 @@
  *
  * Conventions
  *   - plain C, no torch types; every pointer is a DEVICE pointer unless the name ends in _host;
- *   - the caller owns every buffer; the library allocates only inside cfnerf_model (packed weight
- *     copies, activation stash, split-K partials) and frees them in cfnerf_model_destroy;
- *   - every launch is asynchronous on the hipStream_t passed in (pass torch's current stream);
- *     nothing synchronises the host except cfnerf_model_create/destroy and workspace growth;
+ *   - the caller owns every buffer: outputs, parameters, gradients, Adam moments and - through
+ *     cfnerf_workspace_bytes / cfnerf_model_set_workspace - the train-step workspace (activation stash,
+ *     pre-activation gradients, split-K partials).  A cfnerf_model itself owns only the packed weight copies and a
+ *     few KB of scratch, allocated in cfnerf_model_create.  A caller that hands in NO workspace gets a model-owned
+ *     one that grows on demand (the only allocation outside create; it synchronises the device when it grows);
+ *   - every launch is asynchronous on the hipStream_t passed in (pass torch's current stream); on the steady
+ *     path (same N, S, K and workspace as the previous step) no entry point allocates, frees or synchronises;
  *   - return value: 0 = OK, negative = cfnerf_status; cfnerf_last_error() gives a thread-local
  *     message.  No C++ exception crosses the ABI;
  *   - a handle lives on the device that was current at cfnerf_model_create (one handle per device, one
@@ -62,7 +65,7 @@ enum {
     CFNERF_F_LINDISP    = 1 << 1,       /* render_rays(lindisp=True)  RUN:513-514 */
     CFNERF_F_WHITE_BKGD = 1 << 2,       /* raw2outputs(white_bkgd=True) RUN:451-452 */
     CFNERF_F_STASH      = 1 << 3        /* keep activations for cfnerf_render_bwd (implies TRAIN); ONE stash per model: a later
-                                           STASH forward replaces it */
+                                           STASH forward replaces it and bumps cfnerf_model_stash_generation */
 };
 
 int         cfnerf_version(void);
@@ -152,12 +155,27 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
 int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K,
                         float beta1, int64_t n_total, float* d_rgb_map, float* scalars_out, cfnerf_stream s);
 
+/* ---- train-step workspace (ownership contract of SURVEY 8b) -------------------------------------
+ * Bytes of device memory a CFNERF_F_STASH forward + cfnerf_render_bwd of an (N rays, S samples, K latents) batch
+ * need: the activations autograd would have kept for loss.backward() (RUN:1066), the pre-activation gradients
+ * and the split-K weight-gradient partials.  -1 on a bad argument.                                               */
+int64_t cfnerf_workspace_bytes(const cfnerf_cfg* cfg, int64_t N, int S, int K);
+/* Hand the model a caller-owned block (256-byte aligned, e.g. a torch uint8 tensor) to use as that workspace.  The
+ * library then never allocates on the train path: a batch that does not fit is refused with CFNERF_E_NOMEM.  The
+ * block must stay alive until the next cfnerf_model_set_workspace / cfnerf_model_destroy.  (NULL, 0) returns to
+ * the default, a model-owned block grown on demand.  Any stashed forward is dropped.                            */
+int cfnerf_model_set_workspace(cfnerf_model* m, void* workspace, size_t bytes);
+/* Identity of the forward the model's ONE stash currently holds: every CFNERF_F_STASH forward increments it.
+ * 0 = no stashed forward.  Read it right after the forward and pass it to cfnerf_render_bwd.                    */
+uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
+
 /* replaces: loss.backward() (RUN:1066) through raw2outputs, the flows and the MLP for the batch
- * of the last cfnerf_render_fwd(... CFNERF_F_STASH ...) on this model.  d_depth_map may be NULL.
- * d_entropy points to ONE device float, d(loss)/d(loss_entropy) (e.g. beta1); NULL means 0.
- * grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.        */
-int cfnerf_render_bwd(cfnerf_model* m, const float* d_rgb_map, const float* d_depth_map, const float* d_entropy,
-                      float* grad_flat, cfnerf_stream s);
+ * of the cfnerf_render_fwd(... CFNERF_F_STASH ...) whose generation is `stash_generation`; if a later STASH forward
+ * has replaced that stash the call fails (CFNERF_E_INVALID) instead of differentiating the wrong batch.
+ * d_depth_map may be NULL.  d_entropy points to ONE device float, d(loss)/d(loss_entropy) (e.g. beta1); NULL
+ * means 0.  grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.             */
+int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+                      const float* d_entropy, float* grad_flat, cfnerf_stream s);
 
 /* replaces: torch.optim.Adam.step() RUN:339,1067 on the flat buffers (betas .9/.999, eps 1e-8),
  * followed by the re-pack of cfnerf_model_set_params.  step is 1-based.  grad_scale multiplies
@@ -172,7 +190,7 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
  * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).                */
 int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 
-/* bytes currently held by the model's stash / workspaces (diagnostics) */
+/* bytes currently held by the model: packed weights + the bound workspace, whoever owns it (diagnostics) */
 int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
 
 /* seconds^-3 helper for bench.py: average duration (ms) of the last `n` fused-forward launches

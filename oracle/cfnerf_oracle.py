@@ -69,8 +69,9 @@ class OracleCfg:
 
     @property
     def skip(self) -> int:
-        # RUN:327  args.skips = [args.netdepth / 2]
-        return self.netdepth // 2
+        # RUN:327  args.skips = [args.netdepth / 2] - a float: for an odd netdepth `i in self.skips` (MOD:39,171) never
+        # matches and the trunk has no skip concat (-2 equals no layer index)
+        return self.netdepth // 2 if self.netdepth % 2 == 0 else -2
 
 
 def param_shapes(cfg: OracleCfg) -> Dict[str, Tuple[int, ...]]:
@@ -167,6 +168,35 @@ def embed(x: Tensor, multires: int) -> Tensor:
 # --------------------------------------------------------------------------
 # MLP trunk + heads  (MOD:165-186)
 # --------------------------------------------------------------------------
+class relu_override:
+    """TEST HOOK (not part of the restated algorithm).  ``record``: dict that receives every pre-activation
+    (``trunk<i>``, ``views``); ``masks``: dict of 0/1 tensors used INSTEAD of ``pre > 0`` - the gradient tests impose
+    the masks the HIP forward took, so that two fp32 implementations that round a ~0 pre-activation to different
+    sides are compared on the same piecewise-linear function and every other difference must be at fp32 noise."""
+    active = None
+
+    def __init__(self, record=None, masks=None):
+        self.record, self.masks = record, masks
+
+    def __enter__(self):
+        relu_override.active = self
+        return self
+
+    def __exit__(self, *exc):
+        relu_override.active = None
+
+
+def _relu(pre: Tensor, name: str) -> Tensor:
+    hook = relu_override.active
+    if hook is None:
+        return F.relu(pre)
+    if hook.record is not None:
+        hook.record[name] = pre.detach()
+    if hook.masks is not None:
+        return pre * hook.masks[name].to(pre.dtype)
+    return F.relu(pre)
+
+
 def mlp_encode(p: Dict[str, Tensor], x: Tensor, cfg: OracleCfg,
                return_acts: bool = False):
     ic, icv = cfg.input_ch, cfg.input_ch_views
@@ -175,14 +205,14 @@ def mlp_encode(p: Dict[str, Tensor], x: Tensor, cfg: OracleCfg,
     acts = []
     for i in range(cfg.netdepth):                                          # MOD:168
         h = F.linear(h, p[f"pts_linears.{i}.weight"], p[f"pts_linears.{i}.bias"])
-        h = F.relu(h)                                                      # MOD:170
+        h = _relu(h, f"trunk{i}")                                          # MOD:170  F.relu
         acts.append(h)
         if i == cfg.skip:                                                  # MOD:171-172 (input first)
             h = torch.cat([input_pts, h], -1)
     h_alpha = F.linear(h, p["h_alpha_linear.weight"], p["h_alpha_linear.bias"])      # MOD:175
     feature = F.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])      # MOD:176
     h2 = torch.cat([feature, input_views], -1)                                        # MOD:177
-    h2 = F.relu(F.linear(h2, p["views_linears.0.weight"], p["views_linears.0.bias"]))  # MOD:180-181
+    h2 = _relu(F.linear(h2, p["views_linears.0.weight"], p["views_linears.0.bias"]), "views")  # MOD:180-181  F.relu
     h_rgb = F.linear(h2, p["h_rgb_linear.weight"], p["h_rgb_linear.bias"])            # MOD:182
     if return_acts:
         return h_alpha, h_rgb, dict(trunk=acts, feature=feature, views=h2)

@@ -8,6 +8,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+TESTS = os.path.join(ROOT, "tests")
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
+
+# Multi-process GPU tests need FRESH children: a process that has initialised the GPU must never fork-and-exec (on
+# this pool that takes the machine down).  So the fork server is started HERE, at collection time, before any test
+# of this process has touched the GPU; the ranks of tests/test_hip_multirank.py are forked from that clean server.
+FORKSERVER_CTX = None
+if os.path.exists("/dev/kfd"):
+    import multiprocessing as _mp
+    from multiprocessing import forkserver as _fs
+    FORKSERVER_CTX = _mp.get_context("forkserver")
+    _fs.ensure_running()
 
 
 def pytest_configure(config):

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Generate golden vectors by importing the REAL reference (build container only).
 
-Run:  python tests/golden/make_golden.py          (writes tests/golden/*.npz)
+Run:  python tests/golden/make_golden.py [--out DIR] [fixture names ...]
+      (writes DIR/*.npz, default tests/golden/, and DIR/MANIFEST.json: per fixture, the sha256 of every array.
+       tests/test_oracle_golden.py::test_fixtures_match_the_manifest holds the committed files to that manifest and,
+       where /root/reference exists, test_committed_generator_reproduces_the_fixtures re-runs this script and
+       compares every array bit for bit.)
 
 The reference (``/root/reference``, read-only, Python) cannot travel to the GPU
 box, so its outputs are captured here as small fixtures.  A fixture holds only
@@ -273,7 +277,7 @@ def main():
                  ndc=int(not over.get("no_ndc", False)), lindisp=int(over.get("lindisp", False)),
                  white_bkgd=int(over.get("white_bkgd", False)), beta1=beta1,
                  rays=rays_t, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, target=target,
-                 rgb_map=rgbs, disp_map=disp, depth_map=depth, raw_first4=extras["raw"][:4], pts=extras["pts"],
+                 rgb_map=rgbs, disp_map=disp, depth_map=depth, raw=extras["raw"], pts=extras["pts"],
                  loss_entropy=loss_entropy, loss_entropy_numel=extras["loss_entropy"].numel(),
                  loss_nll=loss_nll, loss=loss, mse=mse, psnr=psnr.reshape(-1)[0],
                  rgb_map_eval=rgbs_e, disp_map_eval=disp_e, depth_map_eval=depth_e,
@@ -363,13 +367,149 @@ def main():
                                    rgb_map=rgbs, disp_map=disp, depth_map=depth, raw_first4=extras["raw"][:4],
                                    loss_entropy=extras["loss_entropy"].reshape(-1)[0])
 
-    only = set(sys.argv[1:])                 # optional: regenerate only the named fixtures
+
+    # ================= fixtures added in round 2: each uses its OWN random stream, so the ones above do not move =========
+    # ---------------- G13: ODD netdepth (RUN:327 skips = [netdepth / 2] is a float: no layer matches, no skip concat) ----
+    rng13 = np.random.default_rng(113)
+    cfg = O.OracleCfg(netwidth=64, K_samples=3, netdepth=5)
+    args, kw_train, kw_test, model, p, _ = build_reference_model(R, cfg, 61, tmp, K_samples=3)
+    net = model.module
+    x90 = torch.tensor(rng13.uniform(-1, 1, (12, 90)), dtype=torch.float32)
+    ea = torch.tensor(rng13.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng13.standard_normal((3, 3)), dtype=torch.float32)
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()
+    with torch.no_grad():
+        raw_eval, _ = net(x90, False, True)
+    with ExplicitRandom(normals=[ea, er]):
+        raw_train, ent = net(x90, False, False)
+    shapes = {k: np.array(v.shape) for k, v in net.state_dict().items() if k.startswith("pts_linears") and k.endswith("weight")}
+    out["g13_odd_depth"] = dict(seed=61, netwidth=64, netdepth=5, K=3, x90=x90, eps_alpha=ea, eps_rgb=er, raw_eval=raw_eval,
+                                raw_train=raw_train, loss_entropy=ent.reshape(-1)[0],
+                                **{"shape." + k: v for k, v in shapes.items()})
+
+    # ---------------- G14: BASELINE config 1 (C1): K = 1, N_rand = 256, default width, render() forward only (R4) ----------
+    rng14 = np.random.default_rng(114)
+    cfg = O.OracleCfg(netwidth=256, K_samples=1)
+    args, kw_train, kw_test, model, p, _ = build_reference_model(R, cfg, 62, tmp, K_samples=1)
+    net = model.module
+    rays, (H, W, focal) = fern_rays(rng14, 256)
+    rays_t = torch.tensor(rays)
+    t_rand = torch.tensor(rng14.uniform(0, 1, (256, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng14.standard_normal((1, 1)), dtype=torch.float32)
+    er = torch.tensor(rng14.standard_normal((1, 3)), dtype=torch.float32)
+    with torch.no_grad(), ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., **kw_train)
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, extras_e = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., **kw_test)
+    out["g14_render_c1_k1"] = dict(seed=62, netwidth=256, K=1, H=H, W=W, focal=focal, rays=rays_t, t_rand=t_rand, eps_alpha=ea, eps_rgb=er,
+                                   rgb_map=rgbs, disp_map=disp, depth_map=depth, raw_first4=extras["raw"][:4],
+                                   loss_entropy=extras["loss_entropy"].reshape(-1)[0],
+                                   loss_entropy_shape=np.array(extras["loss_entropy"].shape),
+                                   rgb_map_eval=rgbs_e, disp_map_eval=disp_e, depth_map_eval=depth_e)
+
+    # ---------------- G15: THREE optimiser steps with the reference's own loop lines (RUN:1013-1077): Adam state past the
+    #                  first step (m / sqrt(v) no longer +-1) and the learning-rate decay written after every step ----------
+    rng15 = np.random.default_rng(115)
+    cfg = O.OracleCfg(netwidth=64, K_samples=4)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 63, tmp, K_samples=4)
+    args.lrate_decay = 1                     # decay_steps = 1000: the schedule is visible within three steps
+    n = 24
+    rays, (H, W, focal) = fern_rays(rng15, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng15.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    beta1 = 0.01
+    global_step = 0                          # RUN:820 (start = 0)
+    g15 = dict(seed=63, netwidth=64, K=4, H=H, W=W, focal=focal, rays=rays_t, target=target, beta1=beta1, lrate=args.lrate,
+               lrate_decay=args.lrate_decay, n_steps=3)
+    import math
+    for step in range(3):
+        t_rand = torch.tensor(rng15.uniform(0, 1, (n, 128)), dtype=torch.float32)
+        ea = torch.tensor(rng15.standard_normal((4, 1)), dtype=torch.float32)
+        er = torch.tensor(rng15.standard_normal((4, 3)), dtype=torch.float32)
+        with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+            rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False,
+                                                 **kw_train)
+        nk, eps = 4, 1e-05                                                                  # RUN:1026-1050
+        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+        H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+        loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+        loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+        optimizer.zero_grad()                                                               # RUN:1065-1067
+        loss.backward()
+        optimizer.step()
+        decay_rate = 0.1                                                                    # RUN:1073-1077
+        decay_steps = args.lrate_decay * 1000
+        new_lrate = args.lrate * (decay_rate ** (global_step / decay_steps))
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = new_lrate
+        global_step += 1                                                                    # RUN:1198
+        g15[f"t_rand{step}"], g15[f"eps_alpha{step}"], g15[f"eps_rgb{step}"] = t_rand, ea, er
+        g15[f"loss{step}"] = loss.detach()
+        g15[f"lr_after{step}"] = new_lrate
+    for k, v in model.named_parameters():
+        g15["adam3." + k[len("module."):]] = v.detach().clone()
+    out["g15_three_steps"] = g15
+
+    # ---------------- G16: train step at K = 16 (BASELINE config 4's latent count; the authors train at K = 32) -------------
+    rng16 = np.random.default_rng(116)
+    cfg = O.OracleCfg(netwidth=64, K_samples=16)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 64, tmp, K_samples=16)
+    n = 6
+    rays, (H, W, focal) = fern_rays(rng16, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng16.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    t_rand = torch.tensor(rng16.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng16.standard_normal((16, 1)), dtype=torch.float32)
+    er = torch.tensor(rng16.standard_normal((16, 3)), dtype=torch.float32)
+    with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
+    nk, eps, beta1 = 16, 1e-05, 0.01
+    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    g16 = dict(seed=64, netwidth=64, K=16, H=H, W=W, focal=focal, rays=rays_t, target=target, t_rand=t_rand, eps_alpha=ea, eps_rgb=er,
+               beta1=beta1, rgb_map=rgbs, depth_map=depth, loss=loss.detach(), loss_nll=loss_nll.detach(),
+               loss_entropy=extras["loss_entropy"].mean().detach())
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            g16["grad." + k[len("module."):]] = v.grad.clone()
+    out["g16_train_k16"] = g16
+
+    import hashlib
+    import json
+    argv = sys.argv[1:]
+    out_dir = HERE
+    if "--out" in argv:
+        i = argv.index("--out")
+        out_dir = argv[i + 1]
+        del argv[i:i + 2]
+        os.makedirs(out_dir, exist_ok=True)
+    only = set(argv)                         # optional: regenerate only the named fixtures
+    man_path = os.path.join(out_dir, "MANIFEST.json")
+    manifest = {}
+    if only and os.path.exists(man_path):
+        with open(man_path) as f:
+            manifest = json.load(f)
     for name, d in out.items():
         if only and name not in only:
             continue
-        path = os.path.join(HERE, name + ".npz")
-        np.savez_compressed(path, **t2n(d))
+        arrays = t2n(d)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        manifest[name] = {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] + ":" + str(v.dtype) + str(list(v.shape))
+                          for k, v in sorted(arrays.items())}
         print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+    with open(man_path, "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+        f.write("\n")
 
 
 if __name__ == "__main__":

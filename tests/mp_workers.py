@@ -1,0 +1,54 @@
+"""Rank bodies of the multi-process tests (importable by name from a fork-server child)."""
+import os
+
+
+def trainer_rank(rank, world, port, q, spec):
+    """One rank of a world-size-`world` run of the PRODUCT train step (cfnerf_amd.train.Trainer on the HIP kernels),
+    every rank on cuda:0, exchanging over a gloo group.  Rank 0 reports the parameters after the last step."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import cfnerf_amd                                      # noqa: F401
+        from cfnerf_amd import train as TR
+        from oracle import cfnerf_oracle as O
+        from util_hip import build_model, fern_rays
+        cfg = O.OracleCfg(netwidth=spec["W"], K_samples=spec["K"])
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, kw_train, _, model, p, _ = build_model(cfg, spec["seed"])
+        rng = np.random.default_rng(spec["data_seed"])
+        N = spec["N"]
+        rays, (H, Wd, focal) = fern_rays(rng, N)
+        target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+        lo, hi = TR.shard_bounds(N, rank, world)
+        tr = TR.Trainer(model, lrate=5e-4, lrate_decay=250, beta1=spec["beta1"], world_size=world)
+        torch.manual_seed(1000 + rank)                        # DIFFERENT seeds per rank: the latents must still agree
+        eps_used, losses = [], []
+        for step in range(spec["steps"]):
+            t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+            kw = dict(t_rand=t_rand[lo:hi].cuda())
+            if spec.get("explicit_eps"):
+                kw["eps"] = torch.tensor(np.random.default_rng(7000 + step).standard_normal((spec["K"], 4)), dtype=torch.float32).cuda()
+            else:
+                e = tr._step_eps()                             # what step() is about to use (idempotent)
+                eps_used.append(e.cpu().numpy().copy())
+                kw["eps"] = e
+            sc = tr.step(H, Wd, focal, (rays[0, lo:hi].cuda(), rays[1, lo:hi].cuda()), target[lo:hi].cuda(), **kw)
+            if not spec.get("explicit_eps"):
+                pass
+            s = sc[:2].clone().cpu()
+            dist.all_reduce(s)                                 # loss, nll: contributions sum to the global value
+            losses.append(s.numpy())
+        torch.cuda.synchronize()
+        q.put((rank, "ok", model.module.flat.detach().cpu().numpy(), np.array(losses), np.array(eps_used)))
+        dist.destroy_process_group()
+    except Exception as e:                                     # surface the failure in the parent instead of a timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None))
+        raise

@@ -120,6 +120,42 @@ def test_render_batch_vs_reference_golden(golden, tag):
     close(disp_e, g["disp_map_eval"], atol=ATOL_DISP, rtol=1e-3, what="disp_map_eval")
 
 
+def test_render_config1_k1_vs_reference_golden(golden):
+    """G14 = BASELINE config 1 through render() (RUN:103-170): K = 1 latent sample, N_rand = 256 fern-shaped rays, default
+    width, forward only (the reference's K = 1 train loss is NaN) - train-mode and eval-mode render."""
+    g = golden("g14_render_c1_k1")
+    cfg = cfg_from(g)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    rays = T(g["rays"]).to(DEV)
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(H, W, focal, chunk=8192, rays=rays, near=0., far=1., t_rand=T(g["t_rand"]),
+                                                      eps_alpha=T(g["eps_alpha"]), eps_rgb=T(g["eps_rgb"]), **kw_train)
+    assert list(rgbs.shape) == [256, 3, 1] and list(disp.shape) == [256, 1] and list(extras["raw"].shape) == [256, 128, 1, 4]
+    close(rgbs, g["rgb_map"], what="rgb_map")
+    close(depth, g["depth_map"], what="depth_map")
+    close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    close(extras["raw"][:4], g["raw_first4"], what="raw")
+    assert list(extras["loss_entropy"].shape) == list(g["loss_entropy_shape"])
+    close(extras["loss_entropy"].reshape(-1)[0], g["loss_entropy"], what="loss_entropy")
+    net.sample_alpha, net.sample_rgb = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, extras_e = cfnerf_amd.render(H, W, focal, chunk=8192, rays=rays, near=0., far=1., **kw_test)
+    close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth_e, g["depth_map_eval"], what="depth_map_eval")
+    close(disp_e, g["disp_map_eval"], atol=ATOL_DISP, rtol=1e-3, what="disp_map_eval")
+    # and the same batch in two chunks through batchify_rays (RUN:88-100): bit-identical maps
+    with torch.no_grad():
+        packed = torch.empty(256, 11, device=DEV)
+        from cfnerf_amd import _lib as L
+        ro, rd = rays[0].contiguous(), rays[1].contiguous()
+        L.check(L.lib().cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), 256, 0, 1, 0., 1., L.ptr(packed), L.stream()), "rays_setup")
+        kw = {k: v for k, v in kw_test.items() if k not in ("use_viewdirs", "ndc")}
+        two = cfnerf_amd.batchify_rays(packed, chunk=100, **kw)
+    assert torch.equal(two["rgb_map"], rgbs_e) and torch.equal(two["depth_map"], depth_e)
+
+
 def test_render_c2w_vs_reference_golden(golden):
     g = golden("g6_render_c2w")
     cfg = cfg_from(g)

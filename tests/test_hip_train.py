@@ -13,25 +13,34 @@ pytestmark = pytest.mark.gpu
 T = lambda a: torch.tensor(np.asarray(a))
 DEV = "cuda"
 
-# Gradient tolerances, relative to the largest entry of each tensor.
-#  * heads / flows / feature / views / base Gaussians: plain fp32 re-ordering noise (measured <= 2e-6).
-#  * trunk layers (pts_linears.*): a handful of ReLU masks flip between two fp32 implementations - units whose
-#    pre-activation lies below the fp32 noise of the 2^9-frequency positional encoding (measured: 4 rows of 6144,
-#    one unit each).  Each flip moves a summed gradient by ~1/P; the reference's OWN fp32-vs-fp64 gradients differ by
-#    1e-3 on these tensors (tests/tools/grad_diag.py).  So the trunk check is a max-error bound plus a tight L2 bound.
-G_TIGHT, G_TRUNK_MAX, G_TRUNK_L2 = 2e-4, 6e-3, 3e-3
+# Gradient tolerance: 2e-4 of each tensor's largest entry, for EVERY tensor (measured <= 2e-6 on heads / flows).  The
+# trunk layers are held to it too: ReLU units whose pre-activation lies below the fp32 noise of the 2^9-frequency
+# positional encoding round to different sides in two fp32 implementations (measured: a handful per 10^6 units), so the
+# oracle is differentiated on the masks the HIP forward actually took, after checking that every differing mask sits
+# on a pre-activation smaller than that layer's activation error (util_hip.oracle_train_step_on_hip_masks).  Against
+# fixtures of the real reference - whose masks are the oracle's own - the fixture is corrected by the oracle's
+# gradient difference between the two mask sets, which is exactly the part of the function that changed.
+from util_hip import G_TIGHT, grad_close_tight, oracle_train_step_on_hip_masks
 
 
-def grad_close(g, ref, what, n_flip_tol=0.0):
-    ref = np.asarray(ref, dtype=np.float64)
-    g = g.detach().cpu().double().numpy() if torch.is_tensor(g) else np.asarray(g, dtype=np.float64)
-    scale = max(float(np.abs(ref).max()), 1e-12)
-    assert np.isfinite(g).all(), what
-    if "pts_linears" in what:
-        assert np.abs(g - ref).max() <= max(G_TRUNK_MAX, n_flip_tol) * scale, f"{what}: max err {np.abs(g - ref).max() / scale:.2e} of max"
-        assert np.linalg.norm(g - ref) <= max(G_TRUNK_L2, n_flip_tol) * np.linalg.norm(ref), f"{what}: rel L2 {np.linalg.norm(g - ref) / np.linalg.norm(ref):.2e}"
-    else:
-        close(g, ref, atol=G_TIGHT * scale, rtol=2e-3, what=what)
+def grad_close(g, ref, what):
+    grad_close_tight(g, ref, what)
+
+
+def mask_corrected(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=False, white_bkgd=False):
+    """Per-tensor correction (oracle on the HIP masks) - (oracle on its own masks): added to a gradient of the real
+    reference it gives what the reference would have returned had its ReLUs rounded like the HIP forward's."""
+    _, g_own, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd)
+    _, g_hip, _, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd)
+    return {k: (None if g_own[k] is None else (g_hip[k] - g_own[k]).numpy()) for k in g_own}, n_flips
+
+
+def check_all_grads(net, grad, grads, what=""):
+    for key, (off, cnt) in net.layout.items():
+        if grads[key] is None:
+            assert not grad[off:off + cnt].any(), key
+        else:
+            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key + " " + what)
 
 
 def cfg_from(g):
@@ -58,17 +67,20 @@ def test_train_step_vs_reference_golden(golden, tag):
     close(sc[2], g["mse"], atol=1e-6, rtol=1e-4, what="mse")
     close(sc[3], g["psnr"], atol=1e-4, rtol=1e-4, what="psnr")
     close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    packed = O.pack_rays(H, W, focal, T(g["rays"])[0], T(g["rays"])[1], bool(g["ndc"]), float(g["near"]), float(g["far"]))
+    corr, _ = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]),
+                             bool(g["lindisp"]), bool(g["white_bkgd"]))
     n = 0
     for key, (off, cnt) in net.layout.items():
         gk = grad[off:off + cnt].cpu().numpy()
         if ("grad." + key) in g:
-            grad_close(gk.reshape(g["grad." + key].shape), g["grad." + key], "grad " + key)
+            grad_close(gk.reshape(g["grad." + key].shape), g["grad." + key] + corr[key], "grad " + key)
             n += 1
         elif ("gradrows." + key) in g:
             ref = g["gradrows." + key]
             full = gk.reshape(-1, ref.shape[1])
             scale = float(g["gradnorm." + key]) / np.sqrt(full.size)       # rms entry of the full tensor
-            assert np.abs(full[:2] - ref).max() <= (G_TRUNK_MAX if "pts_linears" in key else G_TIGHT * 10) * 10 * scale, "gradrows " + key
+            assert np.abs(full[:2] - (ref + corr[key][:2])).max() <= G_TIGHT * 100 * scale, "gradrows " + key
             close(np.linalg.norm(full.astype(np.float64)), g["gradnorm." + key], atol=0, rtol=2e-3, what="gradnorm " + key)
             n += 1
         else:
@@ -86,7 +98,10 @@ def test_train_step_vs_reference_golden(golden, tag):
             assert float((d > 2e-5).float().mean()) <= 0.02, f"adam {key}: {float((d > 2e-5).float().mean()):.3%} entries moved"
 
 
-@pytest.mark.parametrize("W,K,N", [(256, 4, 48), (128, 8, 40), (512, 2, 16)])
+@pytest.mark.parametrize("W,K,N", [(256, 4, 48), (128, 8, 40), (512, 2, 16),
+                                   # the latent counts people actually train with: BASELINE config 4 (16), train_NF.sh (32),
+                                   # the reference's default K_samples (64, RUN:631); incl. the authors' W = 512 / h_alpha = 64
+                                   (256, 16, 12), (256, 32, 6), (256, 64, 4), (512, 32, 4), (64, 64, 5), (128, 16, 9)])
 def test_gradients_vs_oracle(W, K, N):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
     _, kw_train, _, model, p, _ = build_model(cfg, 500 + W + K)
@@ -102,14 +117,62 @@ def test_gradients_vs_oracle(W, K, N):
     grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV),
                                eps=torch.cat([er, ea], -1).to(DEV)).cpu()
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
-    scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1)
+    scal, grads, ret, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1)
+    close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map")
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    check_all_grads(net, grad, grads, f"[W={W} K={K} N={N}, {n_flips} masks differ]")
+
+
+def test_train_step_k16_vs_reference_golden(golden):
+    """G16: loss and every parameter gradient of the REAL reference at K = 16 latent samples."""
+    g = golden("g16_train_k16")
+    cfg = cfg_from(g)
+    _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    tr = TR.Trainer(net, beta1=float(g["beta1"]))
+    eps = torch.cat([T(g["eps_rgb"]), T(g["eps_alpha"])], -1).to(DEV)
+    grad = tr.forward_backward(H, W, focal, T(g["rays"]).to(DEV), T(g["target"]).to(DEV), t_rand=T(g["t_rand"]).to(DEV), eps=eps).cpu()
+    close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    close(tr.depth, g["depth_map"], what="depth_map")
+    close(tr.scalars[0].cpu(), g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    close(tr.scalars[1].cpu(), g["loss_nll"], atol=1e-5, rtol=1e-4, what="loss_nll")
+    close(tr.entropy.cpu().reshape(()), g["loss_entropy"], atol=1e-5, rtol=1e-4, what="entropy")
+    packed = O.pack_rays(H, W, focal, T(g["rays"])[0], T(g["rays"])[1], True, 0., 1.)
+    corr, _ = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    n = 0
     for key, (off, cnt) in net.layout.items():
-        if grads[key] is None:
-            assert not grad[off:off + cnt].any()
+        if ("grad." + key) in g:
+            grad_close(grad[off:off + cnt].reshape(g["grad." + key].shape), g["grad." + key] + corr[key], "grad " + key)
+            n += 1
         else:
-            # one flipped ReLU unit moves a summed gradient by ~1/P of its scale: scale the bound for small batches
-            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
+            assert not grad[off:off + cnt].any(), key
+    assert n >= 30
+
+
+def test_three_steps_vs_reference_golden(golden):
+    """G15: three iterations of the reference's own training loop (RUN:1013-1077) with lrate_decay = 1: Adam state past
+    step 1 (m / sqrt(v) no longer +-1) and the learning-rate write-back after every step."""
+    g = golden("g15_three_steps")
+    cfg = cfg_from(g)
+    _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    tr = TR.Trainer(net, lrate=float(g["lrate"]), lrate_decay=int(g["lrate_decay"]), beta1=float(g["beta1"]))
+    rays, target = T(g["rays"]).to(DEV), T(g["target"]).to(DEV)
+    for step in range(int(g["n_steps"])):
+        eps = torch.cat([T(g[f"eps_rgb{step}"]), T(g[f"eps_alpha{step}"])], -1).to(DEV)
+        sc = tr.step(H, W, focal, rays, target, t_rand=T(g[f"t_rand{step}"]).to(DEV), eps=eps).cpu()
+        close(sc[0], g[f"loss{step}"], atol=5e-5, rtol=1e-4, what=f"loss at step {step}")
+        # the rate the NEXT step will use is the one the reference wrote back after this step
+        close(TR.lr_at(tr.lrate, tr.lrate_decay, 0, step + 1), g[f"lr_after{step}"], atol=0, rtol=1e-9, what="lr")
+    for key in net.layout:
+        if ("adam3." + key) in g:
+            d = (net.view(key).cpu().double() - T(g["adam3." + key]).double()).abs()
+            # an entry whose ~0 gradient has the other sign at step 1 moves by up to 2 lr per step; everything else
+            # must agree far below what ignoring the decay would cost (0.2-0.5 % of lr per step ~ 1e-6)
+            assert float(d.max()) <= 3 * 2 * 5e-4 + 1e-6, "adam3 " + key
+            assert float((d > 4e-7).double().mean()) <= 0.03, f"adam3 {key}: {float((d > 4e-7).double().mean()):.3%} entries differ"
 
 
 def test_autograd_path_matches_fused_trainer():
@@ -198,8 +261,10 @@ def test_training_reduces_the_loss():
     assert losses[-20:, 2].mean() < 0.9 * losses[:20, 2].mean(), (losses[:20, 2].mean(), losses[-20:, 2].mean())
 
 
-@pytest.mark.parametrize("D,W,K,N", [(6, 128, 3, 20), (4, 64, 5, 12)])
+@pytest.mark.parametrize("D,W,K,N", [(6, 128, 3, 20), (4, 64, 5, 12), (5, 64, 3, 10), (3, 128, 2, 7)])
 def test_gradients_generic_depth(D, W, K, N):
+    """Even depths have the skip concat after layer D/2; odd depths have none, like the reference (skips = [D / 2] is a
+    float there, RUN:327; fixture G13 pins that against the real reference)."""
     cfg = O.OracleCfg(netdepth=D, netwidth=W, K_samples=K)
     _, kw_train, _, model, p, _ = build_model(cfg, 900 + D, netdepth=D)
     net = model.module
@@ -212,13 +277,26 @@ def test_gradients_generic_depth(D, W, K, N):
     tr = TR.Trainer(net, beta1=0.02)
     grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV)).cpu()
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
-    scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, 0.02)
+    scal, grads, _, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 0.02)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
-    for key, (off, cnt) in net.layout.items():
-        if grads[key] is None:
-            assert not grad[off:off + cnt].any()
-        else:
-            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
+    check_all_grads(net, grad, grads)
+
+
+def test_odd_netdepth_vs_reference_golden(golden):
+    g = golden("g13_odd_depth")
+    cfg = O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g["netdepth"]))
+    _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]), netdepth=cfg.netdepth)
+    net = model.module
+    for i in range(cfg.netdepth):
+        assert list(net.view(f"pts_linears.{i}.weight").shape) == list(g[f"shape.pts_linears.{i}.weight"])
+    x = T(g["x90"]).to(DEV)
+    with torch.no_grad():
+        raw_t, ent = net(x, False, False, eps_alpha=T(g["eps_alpha"]), eps_rgb=T(g["eps_rgb"]))
+        net.sample_alpha, net.sample_rgb = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+        raw_e, _ = net(x, False, True)
+    close(raw_t, g["raw_train"], what="raw_train")
+    close(ent.reshape(-1)[0], g["loss_entropy"], what="loss_entropy")
+    close(raw_e, g["raw_eval"], what="raw_eval")
 
 
 def test_depth_gradient_path_matches_oracle():
@@ -246,37 +324,42 @@ def test_depth_gradient_path_matches_oracle():
     g_hip = net.flat.grad.cpu()
     q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
-    r = O.render_rays(q, packed, cfg, ea, er, True, t_rand, white_bkgd=True)
-    loss_o = loss_of(r["rgb_map"], r["depth_map"], r["loss_entropy"], "cpu")
-    loss_o.backward()
+    from util_hip import hip_relu_masks
+    _, masks = hip_relu_masks(net, N * 128)
+    with O.relu_override(masks=masks):                                  # the function the HIP forward evaluated (see header)
+        r = O.render_rays(q, packed, cfg, ea, er, True, t_rand, white_bkgd=True)
+        loss_o = loss_of(r["rgb_map"], r["depth_map"], r["loss_entropy"], "cpu")
+        loss_o.backward()
     close(loss, loss_o, atol=1e-6, rtol=1e-5, what="loss")
     for key, (off, cnt) in net.layout.items():
         if q[key].grad is None:
             assert not g_hip[off:off + cnt].any()
         else:
-            grad_close(g_hip[off:off + cnt].reshape(q[key].grad.shape), q[key].grad.numpy(), "grad " + key, n_flip_tol=40.0 / (N * 128))
+            grad_close(g_hip[off:off + cnt].reshape(q[key].grad.shape), q[key].grad.numpy(), "grad " + key)
 
 
-def test_full_size_train_step_properties_config2():
-    """configs[1] at full size (1024 rays x 128 samples x K=4, W=256), where the oracle is too slow to be the checker:
-    size-independent properties of the train step.
+@pytest.mark.parametrize("tag,N,K,ndc", [("C2", 1024, 4, True), ("C3", 4096, 8, False), ("C4 shard (1 of 8 ranks)", 1024, 16, True)])
+def test_full_size_train_step_properties(tag, N, K, ndc):
+    """BASELINE configs 2, 3 and one rank's shard of config 4 at FULL size (W = 256, S = 128; C3: no NDC, near 1.2 /
+    far 8 as SURVEY 8d), where the oracle is too slow to be the checker: size-independent properties of the train step.
       * determinism: no atomics, fixed reduction order -> the same step twice gives bit-identical gradients;
       * shard additivity (the multi-GPU contract): the gradients of the two half batches, each taken with
         world_size=2 semantics (nll / (3 N_total), beta1 / world on the shard's entropy), sum to the full-batch gradient;
       * ray-permutation invariance: shuffling the rays of the batch only re-orders the sums."""
-    N, K = 1024, 4
     cfg = O.OracleCfg(netwidth=256, K_samples=K)
-    _, kw_train, _, model, p, _ = build_model(cfg, 3)
-    rng = np.random.default_rng(17)
-    rays, (H, W, focal) = fern_rays(rng, N)
+    _, kw_train, _, model, p, _ = build_model(cfg, 3, no_ndc=not ndc)
+    rng = np.random.default_rng(17 + K)
+    rays, (H, W, focal) = fern_rays(rng, N) if ndc else fern_rays(rng, N, H=512, W=512, focal=600.0)
     rays = rays.to(DEV)
+    near, far = (0., 1.) if ndc else (1.2, 8.0)
     target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32, device=DEV)
     t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32, device=DEV)
     eps = torch.tensor(rng.standard_normal((K, 4)), dtype=torch.float32, device=DEV)
 
     def grad(sel, world):
         tr = TR.Trainer(model, beta1=0.01, world_size=world)
-        g = tr.forward_backward(H, W, focal, (rays[0, sel], rays[1, sel]), target[sel].contiguous(), t_rand=t_rand[sel].contiguous(), eps=eps)
+        g = tr.forward_backward(H, W, focal, (rays[0, sel], rays[1, sel]), target[sel].contiguous(), t_rand=t_rand[sel].contiguous(), eps=eps,
+                                ndc=ndc, near=near, far=far)
         return g.clone(), tr.scalars.clone()
 
     full = torch.arange(N, device=DEV)
@@ -284,6 +367,7 @@ def test_full_size_train_step_properties_config2():
     g2, s2 = grad(full, 1)
     assert torch.equal(g1, g2) and torch.equal(s1, s2), "train step is not deterministic"
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert torch.isfinite(s1).all()
 
     ga, sa = grad(full[: N // 2], 2)
     gb, sb = grad(full[N // 2:], 2)
@@ -295,6 +379,96 @@ def test_full_size_train_step_properties_config2():
     gp, sp = grad(perm, 1)
     assert float((gp - g1).abs().max()) <= 2e-5 * scale, float((gp - g1).abs().max()) / scale
     close(sp.cpu(), s1.cpu(), atol=1e-5, rtol=1e-5, what="scalars under permutation")
+    model.module.release_workspace()
+
+
+def test_stale_stash_is_refused_and_workspace_contract():
+    """One stash per model: a backward whose forward has been overwritten by a later grad-enabled forward fails loudly
+    (it used to differentiate the wrong batch silently).  And the ownership contract of the C ABI: with a caller-owned
+    workspace the library refuses a batch that does not fit instead of allocating."""
+    import ctypes as C
+    from cfnerf_amd import _lib as L
+    cfg = O.OracleCfg(netwidth=64, K_samples=3)
+    _, kw_train, _, model, p, optimizer = build_model(cfg, 5)
+    net = model.module
+    rng = np.random.default_rng(3)
+    ra, (H, Wd, focal) = fern_rays(rng, 16)
+    rb, _ = fern_rays(rng, 24)
+    out_a = cfnerf_amd.render(H, Wd, focal, rays=ra.to(DEV), **kw_train)
+    out_b = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)          # replaces A's stash
+    loss = out_a[0].mean() + out_b[0].mean()
+    with pytest.raises(RuntimeError, match="stale stash"):
+        loss.backward()
+    # the last forward alone is fine, also twice (retain_graph): the stash is read, not consumed
+    out_c = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    optimizer.zero_grad()
+    out_c[0].mean().backward(retain_graph=True)
+    g1 = net.flat.grad.clone()
+    optimizer.zero_grad()
+    out_c[0].mean().backward()
+    assert torch.equal(g1, net.flat.grad)
+    # ---- workspace contract through the C ABI
+    lib = L.lib()
+    need_small = lib.cfnerf_workspace_bytes(C.byref(net.cfg), 8, 128, 3)
+    need_big = lib.cfnerf_workspace_bytes(C.byref(net.cfg), 64, 128, 3)
+    assert 0 < need_small < need_big
+    assert lib.cfnerf_workspace_bytes(C.byref(net.cfg), 8, 0, 3) == -1
+    ws = torch.empty(need_small, dtype=torch.uint8, device=DEV)
+    net._ws = None
+    L.check(lib.cfnerf_model_set_workspace(net.handle, C.c_void_p(ws.data_ptr()), ws.numel()), "set_workspace")
+    assert lib.cfnerf_model_stash_generation(net.handle) == 0                        # re-binding drops the stashed forward
+    before = lib.cfnerf_model_workspace_bytes(net.handle)
+    N, S, K = 64, 128, 3
+    rays = torch.zeros(N, 11, device=DEV)
+    rays[:, 5] = -1.
+    rays[:, 7] = 1.
+    rays[:, 10] = -1.
+    tv = cfnerf_amd.api.t_vals_table(DEV)
+    eps = torch.zeros(K, 4, device=DEV)
+    o3, o1, o2, ent = torch.empty(N, 3, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, K, device=DEV), torch.zeros(1, device=DEV)
+
+    def fwd(n):
+        return lib.cfnerf_render_fwd(net.handle, L.ptr(rays[:n].contiguous()), L.ptr(tv), None, None, L.ptr(eps), n, S, K, L.F_STASH | L.F_TRAIN,
+                                     L.ptr(o3), L.ptr(o1), L.ptr(o2), None, None, None, None, L.ptr(ent), L.stream())
+    assert fwd(N) == -4 and b"cfnerf_workspace_bytes" in lib.cfnerf_last_error()       # CFNERF_E_NOMEM, nothing allocated
+    assert lib.cfnerf_model_workspace_bytes(net.handle) == before
+    assert fwd(8) == 0                                                                # fits: runs inside the caller's block
+    gen = lib.cfnerf_model_stash_generation(net.handle)
+    assert gen > 0
+    grad = torch.empty(net.n_params, device=DEV)
+    d_rgb = torch.zeros(8, 3, K, device=DEV)
+    assert lib.cfnerf_render_bwd(net.handle, gen + 1, L.ptr(d_rgb), None, None, L.ptr(grad), L.stream()) == -1
+    assert lib.cfnerf_render_bwd(net.handle, gen, L.ptr(d_rgb), None, None, L.ptr(grad), L.stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(grad).all()
+    L.check(lib.cfnerf_model_set_workspace(net.handle, None, 0), "set_workspace")      # back to the model-owned default
+    assert fwd(N) == 0
+    torch.cuda.synchronize()
+
+
+def test_stash_rebinding_when_the_tile_count_grows_while_points_shrink():
+    """P = N * S shrinks (1024 x 128 -> 1000 x 130) while the tile count N * ceil(S / 64) grows (2048 -> 3000): every
+    buffer of the workspace, including the ReLU bit words that are indexed by TILE, is laid out for the current
+    (N, S, K), so the second step's gradients equal those of a fresh model."""
+    cfg = O.OracleCfg(netwidth=64, K_samples=2)
+    rng = np.random.default_rng(8)
+
+    def step(model, N, S):
+        r = np.random.default_rng(100 + S)
+        rays, (H, Wd, focal) = fern_rays(r, N)
+        tv = torch.linspace(0., 1., S)
+        tr = TR.Trainer(model, beta1=0.01)
+        g = tr.forward_backward(H, Wd, focal, rays.to(DEV), torch.tensor(r.uniform(0, 1, (N, 3)), dtype=torch.float32, device=DEV),
+                                t_rand=torch.tensor(r.uniform(0, 1, (N, S)), dtype=torch.float32, device=DEV),
+                                eps=torch.tensor(r.standard_normal((2, 4)), dtype=torch.float32, device=DEV), t_vals=tv.to(DEV))
+        return g.clone()
+    _, _, _, m1, _, _ = build_model(cfg, 77)
+    step(m1, 1024, 128)
+    g_after = step(m1, 1000, 130)
+    _, _, _, m2, _, _ = build_model(cfg, 77)
+    g_fresh = step(m2, 1000, 130)
+    assert torch.equal(g_after, g_fresh)
+    assert torch.isfinite(g_after).all()
 
 
 @pytest.mark.parametrize("seed", list(range(8)))
@@ -303,8 +477,8 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     white background, jitter on or off): render outputs, loss and every gradient against the CPU oracle."""
     rng = np.random.default_rng(9000 + seed)
     W = int(rng.choice([64, 128, 256]))
-    D = int(rng.choice([4, 6, 8]))
-    K = int(rng.integers(2, 7))
+    D = int(rng.choice([4, 5, 6, 8]))
+    K = int(rng.choice([2, 3, 4, 5, 6, 16, 32]))
     ha, hr = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
     N = int(rng.integers(3, 24))
     ndc = bool(rng.integers(0, 2))
@@ -326,14 +500,9 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
                                eps=torch.cat([er, ea], -1).to(DEV), near=near, far=far, ndc=ndc, lindisp=lindisp, white_bkgd=wb,
                                perturb=1. if perturb else 0.).cpu()
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
-    scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb)
+    scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb)
     what = f"[W={W} D={D} K={K} ha={ha} hr={hr} N={N} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
     close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map " + what)
     close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)
-    for key, (off, cnt) in net.layout.items():
-        if grads[key] is None:
-            assert not grad[off:off + cnt].any(), key
-        else:
-            grad_close(grad[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), "grad " + key + " " + what,
-                       n_flip_tol=40.0 / (N * 128))
+    check_all_grads(net, grad, grads, what)

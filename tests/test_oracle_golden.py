@@ -219,3 +219,144 @@ def test_seeded_implicit_draw_order(golden):
     close(r["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5)
     close(r["raw"][:4], g["raw_first4"], atol=5e-6, rtol=5e-5)
     close(r["loss_entropy"], g["loss_entropy"], atol=5e-6, rtol=5e-5)
+
+
+# ------------------------------------------------------------------ fixtures added in round 2
+def test_odd_netdepth_has_no_skip_concat(golden):
+    """G13: args.skips = [netdepth / 2] is a float (RUN:327); at netdepth 5 no layer index equals 2.5, so the reference
+    builds W x W trunk layers throughout and never concatenates (MOD:39,171).  The oracle mirrors that."""
+    g = golden("g13_odd_depth")
+    cfg = O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g["netdepth"]))
+    shapes = O.param_shapes(cfg)
+    for i in range(cfg.netdepth):
+        assert list(g[f"shape.pts_linears.{i}.weight"]) == list(shapes[f"pts_linears.{i}.weight"])
+        assert shapes[f"pts_linears.{i}.weight"][1] == (63 if i == 0 else 64)
+    p = O.make_params(cfg, int(g["seed"]))
+    ea, er = T(g["eps_alpha"]), T(g["eps_rgb"])
+    raw_t, ent = O.nerf_flows_forward(p, T(g["x90"]), ea, er, cfg, is_test=False)
+    close(raw_t, g["raw_train"], what="raw_train")
+    close(ent, g["loss_entropy"], atol=2e-6, rtol=1e-5, what="loss_entropy")
+    ea0, er0 = ea.clone(), er.clone()
+    ea0[-1] = 0
+    er0[-1] = 0
+    raw_e, _ = O.nerf_flows_forward(p, T(g["x90"]), ea0, er0, cfg, is_test=True)
+    close(raw_e, g["raw_eval"], what="raw_eval")
+
+
+def test_render_config1_k1(golden):
+    """G14 = BASELINE config 1: K = 1, N_rand = 256, default width, forward only (the K = 1 train loss is NaN, R4)."""
+    g = golden("g14_render_c1_k1")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    ea, er = T(g["eps_alpha"]), T(g["eps_rgb"])
+    r = O.render(p, H, W, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=T(g["t_rand"]))
+    assert list(r["rgb_map"].shape) == [256, 3, 1]
+    close(r["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(r["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5, what="depth_map")
+    close(r["disp_map"], g["disp_map"], atol=5e-5, rtol=5e-5, what="disp_map")
+    close(r["raw"][:4], g["raw_first4"], atol=5e-6, rtol=5e-5, what="raw")
+    close(r["loss_entropy"], g["loss_entropy"], atol=5e-6, rtol=5e-5, what="entropy")
+    assert list(g["loss_entropy_shape"]) == [256 * 128, 1, 1]
+    e = O.render(p, H, W, focal, cfg, torch.zeros_like(ea), torch.zeros_like(er), False, rays=(rays[0], rays[1]), t_rand=None)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")   # K = 1: the only latent is the zeroed last one
+    close(e["depth_map"], g["depth_map_eval"], atol=5e-6, rtol=5e-5, what="depth_eval")
+
+
+def test_three_optimizer_steps(golden):
+    """G15: three iterations of the reference's own loop (forward, loss, backward, Adam, learning-rate write-back,
+    RUN:1013-1077) with lrate_decay = 1, so that the decay is visible: the oracle's train_step + adam_step + the
+    schedule of RUN:1073-1077 land on the same parameters."""
+    g = golden("g15_three_steps")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    packed = O.pack_rays(H, W, focal, rays[0], rays[1], True, 0., 1.)
+    params, state = {k: v.clone() for k, v in p.items()}, {}
+    lr = float(g["lrate"])
+    for step in range(int(g["n_steps"])):
+        scal, grads, _ = O.train_step(params, packed, T(g["target"]), cfg, T(g[f"eps_alpha{step}"]), T(g[f"eps_rgb{step}"]),
+                                      T(g[f"t_rand{step}"]), float(g["beta1"]))
+        close(scal["loss"], g[f"loss{step}"], atol=2e-5, rtol=2e-5, what=f"loss at step {step}")
+        params = O.adam_step(params, grads, state, step + 1, lr)
+        lr = O.lr_schedule(float(g["lrate"]), int(g["lrate_decay"]), step)     # global_step BEFORE its increment (RUN:1075,1198)
+        close(lr, g[f"lr_after{step}"], atol=0, rtol=1e-12, what="lr")
+    for k in p:
+        if ("adam3." + k) in g:
+            d = np.abs(params[k].numpy().astype(np.float64) - g["adam3." + k])
+            # sign flips of ~0 gradients at step 1 move an entry by up to 2 lr; everything else agrees to fp32 noise
+            assert d.max() <= 3 * 2 * 5e-4 + 1e-6, k
+            assert (d > 3e-7).mean() <= 0.02, f"{k}: {(d > 3e-7).mean():.3%} entries differ"
+
+
+def test_train_step_k16(golden):
+    """G16: loss and every gradient at K = 16 latent samples (BASELINE config 4's count)."""
+    g = golden("g16_train_k16")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    packed = O.pack_rays(int(g["H"]), int(g["W"]), float(g["focal"]), rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret = O.train_step(p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    close(ret["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(scal["loss"], g["loss"], rtol=2e-5, what="loss")
+    n = 0
+    for k in p:
+        if ("grad." + k) in g:
+            ref = g["grad." + k]
+            scale = max(1e-7, float(np.abs(ref).max()))
+            close(grads[k], ref, atol=2e-4 * scale, rtol=1e-3, what="grad " + k)
+            n += 1
+    assert n >= 30
+
+
+def _manifest():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        return json.load(f)
+
+
+def _digest(v):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] + ":" + str(v.dtype) + str(list(v.shape))
+
+
+def test_fixtures_match_the_manifest(golden):
+    """Every committed .npz holds exactly the arrays (names, dtypes, shapes, bytes) the committed generator wrote:
+    MANIFEST.json is produced by tests/golden/make_golden.py in the same run as the fixtures."""
+    import glob
+    import os
+    from conftest import GOLDEN
+    man = _manifest()
+    names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    assert names == sorted(man), (set(names) ^ set(man))
+    for name in names:
+        g = golden(name)
+        assert sorted(g) == sorted(man[name]), (name, set(g) ^ set(man[name]))
+        for k, v in g.items():
+            assert _digest(v) == man[name][k], (name, k)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/model"), reason="the reference only exists in the build container")
+def test_committed_generator_reproduces_the_fixtures(tmp_path):
+    """Build container only: re-run the committed generator against the real reference and compare every array of every
+    fixture with the committed files bit for bit (fixtures can never drift from the recipe that is said to make them)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--out", str(tmp_path)], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    man = _manifest()
+    import json
+    with open(tmp_path / "MANIFEST.json") as f:
+        assert json.load(f) == man
+    for name in man:
+        new = dict(np.load(tmp_path / (name + ".npz"), allow_pickle=False))
+        old = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+        assert sorted(new) == sorted(old), name
+        for k in new:
+            assert new[k].dtype == old[k].dtype and new[k].shape == old[k].shape and new[k].tobytes() == old[k].tobytes(), (name, k)
