@@ -56,6 +56,9 @@ static int model_init_device(cfnerf_model* m) {
         HIPCHK(hipEventCreate(&m->ev0[i]));
         HIPCHK(hipEventCreate(&m->ev1[i]));
     }
+    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     m->ws_bytes = pbytes + sizeof(NetTab);
     // launch attributes and occupancy belong to (kernel, device): set here, with the model's device current
     HIPCHK(fused_fwd_set_attributes(cfg->netwidth, cfg->h_alpha_size, &m->fwd_blocks_per_cu));
@@ -165,6 +168,9 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     m->stash.release();
     m->bwd.release();
     for (int i = 0; i < kNumTimers; ++i) { if (m->ev0[i]) hipEventDestroy(m->ev0[i]); if (m->ev1[i]) hipEventDestroy(m->ev1[i]); }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
+    if (m->side) hipStreamDestroy(m->side);
     delete m;
     return CFNERF_OK;
 }
@@ -328,7 +334,8 @@ int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m) { return m ? (int64_
 int64_t cfnerf_workspace_bytes(const cfnerf_cfg* cfg, int64_t N, int S, int K) {
     if (!cfg) { fail(CFNERF_E_INVALID, "cfg is NULL"); return -1; }
     if (const char* why = validate_cfg(*cfg)) { fail(CFNERF_E_UNSUPPORTED, "%s", why); return -1; }
-    if (N < 0 || S < 1 || K < 1 || K > kMaxK) { fail(CFNERF_E_INVALID, "bad N/S/K"); return -1; }
+    if (K < 1 || K > kMaxK) { fail(CFNERF_E_UNSUPPORTED, "K_samples must be in [1,%d], got %d", kMaxK, K); return -1; }
+    if (N < 0 || S < 1) { fail(CFNERF_E_INVALID, "bad N/S"); return -1; }
     return (int64_t)workspace_bytes_for(*cfg, N, S, K);
 }
 

@@ -39,7 +39,9 @@ struct DwTile {
     int32_t nseg, seg_row[4];                             // destination row segments (concatenated flow heads)
     uint32_t seg_dst[4];
     int32_t dst_ld, dst_col;
-    int32_t gk, wk;                                       // small kernel: waves along k, k-tiles per wave (GN = 8 / gk)
+    int32_t gk, wk;                                       // small kernel: waves along k, k-tiles per wave (GN = 8 / gk);
+                                                          // big kernel: gk = wave arrangement (0: 2 x 4, 1: 1 x 8 for N <= 128)
+    int32_t nsplit, pad_;                                 // point splits of this tile (blocks per tile)
 };
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };
@@ -60,7 +62,7 @@ struct BwdPlan {
     std::vector<RedSeg> segs;
     hipEvent_t uploaded = nullptr;                        // recorded after the descriptor uploads of the last rebuild
     uint64_t bind_serial = ~0ull;                         // Stash::bind_serial the descriptors were built for
-    int ns_big = 0, ns_small = 0;
+    int n_blocks_wide = 0;                                // blocks[0, n_blocks_wide): 2 x 4 tiles; the rest: 1 x 8 tiles
     void release() {
         if (uploaded) (void)hipEventDestroy(uploaded);
         uploaded = nullptr; bind_serial = ~0ull;

@@ -430,63 +430,71 @@ void bwd_data_kernel(const BwdArgs A) {
 typedef const float __attribute__((address_space(1)))* gcf_ptr;      // explicit global address space: the pointers
 typedef float __attribute__((address_space(1)))* gf_ptr;             // come out of a struct in memory (else flat_load)
 
+// Output of a big tile (always ONE destination tensor: the concatenated flow heads are small jobs).
+// TK: MFMA tiles of a wave along k (2: the 2 x 4 wave arrangement, columns k + 2i + tk; 1: the 1 x 8 arrangement, column k + i)
+template <int TK>
 __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const f32x16 (&acc)[4][2], int n_base, int k_base, int lane) {
+    const int kcol = k_base + TK * (lane & 31);
+    gf_ptr o = out + ((size_t)t.seg_dst[0] + t.dst_col + kcol);
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int tk = 0; tk < 2; ++tk) {
-            const int k = k_base + 2 * (lane & 31) + tk;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n_base + 4 * frag_row(r, lane) + tn;
-                if (n < t.N && k < t.K) {
-                    int sg = 0;
-                    if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
-                    if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
-                    if (t.nseg > 3 && n >= t.seg_row[3]) sg = 3;
-                    const uint32_t dst = sg == 0 ? t.seg_dst[0] : sg == 1 ? t.seg_dst[1] : sg == 2 ? t.seg_dst[2] : t.seg_dst[3];
-                    const int row0 = sg == 0 ? t.seg_row[0] : sg == 1 ? t.seg_row[1] : sg == 2 ? t.seg_row[2] : t.seg_row[3];
-                    out[(size_t)dst + (size_t)(n - row0) * t.dst_ld + t.dst_col + k] = acc[tn][tk][r];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int n = n_base + 4 * frag_row(r, lane) + tn;
+            if (n < t.N) {
+                gf_ptr row = o + (size_t)n * t.dst_ld;
+                if (kcol < t.K) row[0] = acc[tn][0][r];
+                if (TK == 2 && kcol + 1 < t.K) row[1] = acc[tn][1][r];
             }
         }
 }
 
-// ---- 4a. big tiles (256 x 256 per workgroup, 8 waves = 2 (n) x 4 (k), each 128 x 64): operands are staged
-//      through double-buffered LDS (32 points per stage) with register prefetch, so every dY / X element is
-//      read from HBM exactly once and the loads of stage s+1 fly under the 128 MFMAs per wave of stage s.
+// ---- 4a. big tiles (256 x 256 per workgroup, 8 waves): operands are staged through double-buffered LDS (32 points
+//      per stage) with register prefetch, so every dY / X element is read from HBM exactly once and the loads of stage
+//      s+1 fly under the MFMAs of stage s.  Wave arrangement per tile (DwTile::gk): 0 = 2 (n) x 4 (k), each wave
+//      128 x 64 (128 MFMAs per stage); 1 = 1 x 8, each wave 128 x 32, for tiles with N <= 128 (the views layer), whose
+//      blocks then do half the MFMAs per stage and get twice the points, instead of idling half their waves.
+//      Loader: buffer loads through one descriptor per operand that covers exactly the block's point range, so rows past
+//      the range and columns past the matrix come back as zeros from the hardware bounds check, the per-lane offsets are
+//      set up once and a stage advances ONE scalar offset - no per-stage address arithmetic on the vector pipe, which on
+//      this chip would come straight out of the MFMA issue slots.
 constexpr int kDwRows = 32;                   // points per LDS stage
 constexpr int kDwThreads = 512;
-template <int PREC>
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int PREC, int ARR>
 __global__ __launch_bounds__(kDwThreads, 2)
-void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
-                   const float* __restrict__ zeros) {
+void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                 // [2][32][256]
     float* Bs = smem + 2 * kDwRows * 256;             // [2][32][256]
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
     const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
-    const int wn = wave >> 2, wk = wave & 3;
-    const int64_t pb = blk.pb, pe = blk.pe;
-    gcf_ptr gy = (gcf_ptr)t.dY, gx = (gcf_ptr)t.X;
-    // loader geometry: thread -> (row = tid / 64 + 8 * pass, 16-B column c = tid % 64)
+    constexpr bool arr1 = ARR == 1;                   // the wave arrangement is a property of the launch (two register
+                                                      // allocations: one kernel holding both loop nests spilt its accumulators)
+    const int wn = arr1 ? 0 : wave >> 2, wk = arr1 ? wave : wave & 3;
+    const int rows = (int)(blk.pe - blk.pb);          // a split's point range is far below 2^31 bytes / row
+    // loader geometry: thread -> (row = tid / 64 + 8 * q, 16-B column c = tid % 64)
     const int lrow = tid >> 6, lc = tid & 63;
     const bool a_col_ok = t.n0 + 4 * lc + 4 <= t.Npad, b_col_ok = t.k0 + 4 * lc + 4 <= t.Kpad;
-    const int a_col = a_col_ok ? t.n0 + 4 * lc : 0, b_col = b_col_ok ? t.k0 + 4 * lc : 0;
-    // Invalid elements (rows past the slab, columns past the matrix) are fetched from a zero page: the select is on
-    // the ADDRESS, so nothing consumes the loaded registers until the LDS store after the MFMA block.
-    gcf_ptr zp = (gcf_ptr)zeros;
+    const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.dY + blk.pb * t.ldY), 0, rows * t.ldY * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.X + blk.pb * t.ldX), 0, rows * t.ldX * 4, 0x00020000);
+    int va[4], vb[4];                                 // byte offsets of this thread's four rows of a stage; out of range = zeros
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        va[q] = a_col_ok ? ((lrow + 8 * q) * t.ldY + t.n0 + 4 * lc) * 4 : 0x7ffffff0;
+        vb[q] = b_col_ok ? ((lrow + 8 * q) * t.ldX + t.k0 + 4 * lc) * 4 : 0x7ffffff0;
+    }
+    const int sa_step = kDwRows * t.ldY * 4, sb_step = kDwRows * t.ldX * 4;
+    int sa = 0, sb = 0;                               // scalar stage offsets
     f32x4 ra[4], rb[4];
-    auto gload = [&](int64_t p) {
+    auto gload = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t pr = p + lrow + 8 * q;
-            gcf_ptr pa = (pr < pe && a_col_ok) ? gy + pr * t.ldY + a_col : zp;
-            gcf_ptr pbk = (pr < pe && b_col_ok) ? gx + pr * t.ldX + b_col : zp;
-            ra[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
-            rb[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pbk);
+            ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, va[q], sa, 0));
+            rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_desc, vb[q], sb, 0));
         }
+        sa += sa_step; sb += sb_step;
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -512,18 +520,19 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const bool active = (t.n0 + 128 * wn < t.N) && (t.k0 + 64 * wk < t.K);     // wave-uniform
+    const int k_wave = arr1 ? 32 * wk : 64 * wk;
+    const bool active = (t.n0 + 128 * wn < t.N) && (t.k0 + k_wave < t.K);     // wave-uniform
     const int i = lane & 31, kk = lane >> 5;
     const float* a_rd = As + kk * 256 + 128 * wn + 4 * i;
-    const float* b_rd = Bs + kk * 256 + 64 * wk + 2 * i;
+    const float* b_rd = Bs + kk * 256 + (arr1 ? 32 * wk + i : 64 * wk + 2 * i);
 
-    gload(pb);
+    gload();
     sstore(0);
     __syncthreads();
     int buf = 0;
-    for (int64_t p = pb; p < pe; p += kDwRows) {
-        const bool more = p + kDwRows < pe;
-        if (more) gload(p + kDwRows);
+    for (int p = 0; p < rows; p += kDwRows) {
+        const bool more = p + kDwRows < rows;
+        if (more) gload();
         __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
         if (active) {
             if (PREC == PREC_BF16X3) {
@@ -531,14 +540,18 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
 #pragma unroll
                 for (int c16 = 0; c16 < kDwRows / 16; ++c16) {
                     const float* ar = As + (buf * kDwRows + c16 * 16 + 8 * kk) * 256 + 128 * wn + 4 * i;
-                    const float* br = Bs + (buf * kDwRows + c16 * 16 + 8 * kk) * 256 + 64 * wk + 2 * i;
+                    const float* br = Bs + (buf * kDwRows + c16 * 16 + 8 * kk) * 256 + (arr1 ? 32 * wk + i : 64 * wk + 2 * i);
                     u32x4 wa[8];
                     unsigned wb0[8], wb1[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         wa[e] = *reinterpret_cast<const u32x4*>(ar + e * 256);
-                        const f32x2 t2 = *reinterpret_cast<const f32x2*>(br + e * 256);
-                        wb0[e] = __float_as_uint(t2[0]); wb1[e] = __float_as_uint(t2[1]);
+                        if (arr1) {
+                            wb0[e] = __float_as_uint(br[e * 256]); wb1[e] = 0u;
+                        } else {
+                            const f32x2 t2 = *reinterpret_cast<const f32x2*>(br + e * 256);
+                            wb0[e] = __float_as_uint(t2[0]); wb1[e] = __float_as_uint(t2[1]);
+                        }
                     }
                     bf16x8 bh[2], bl[2];
                     {
@@ -559,27 +572,39 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
                             l[q] = __builtin_amdgcn_perm(wa[2 * q + 1][tn], wa[2 * q][tn], 0x07060302u);
                         }
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, h), al = __builtin_bit_cast(bf16x8, l);
-#pragma unroll
-                        for (int tk = 0; tk < 2; ++tk) {
-                            acc[tn][tk] = CFN_MFMA16(al, bh[tk], acc[tn][tk]);
-                            acc[tn][tk] = CFN_MFMA16(ah, bl[tk], acc[tn][tk]);
-                            acc[tn][tk] = CFN_MFMA16(ah, bh[tk], acc[tn][tk]);
+                        acc[tn][0] = CFN_MFMA16(al, bh[0], acc[tn][0]);
+                        acc[tn][0] = CFN_MFMA16(ah, bl[0], acc[tn][0]);
+                        acc[tn][0] = CFN_MFMA16(ah, bh[0], acc[tn][0]);
+                        if (!arr1) {
+                            acc[tn][1] = CFN_MFMA16(al, bh[1], acc[tn][1]);
+                            acc[tn][1] = CFN_MFMA16(ah, bl[1], acc[tn][1]);
+                            acc[tn][1] = CFN_MFMA16(ah, bh[1], acc[tn][1]);
                         }
                     }
                 }
             } else {
-            const float* ar = a_rd + buf * kDwRows * 256;
-            const float* br = b_rd + buf * kDwRows * 256;
+                const float* ar = a_rd + buf * kDwRows * 256;
+                const float* br = b_rd + buf * kDwRows * 256;
+                if (!arr1) {
 #pragma unroll 4
-            for (int pp = 0; pp < kDwRows / 2; ++pp) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
-                const f32x2 bv = *reinterpret_cast<const f32x2*>(br + pp * 512);
+                    for (int pp = 0; pp < kDwRows / 2; ++pp) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
+                        const f32x2 bv = *reinterpret_cast<const f32x2*>(br + pp * 512);
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
-                    acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
+                        for (int tn = 0; tn < 4; ++tn) {
+                            acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
+                            acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int pp = 0; pp < kDwRows / 2; ++pp) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
+                        const float bv = br[pp * 512];
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) acc[tn][0] = CFN_MFMA(av[tn], bv, acc[tn][0]);
+                    }
                 }
-            }
             }
         }
         __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
@@ -587,8 +612,11 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         __syncthreads();
         buf ^= 1;
     }
-    if (active)
-        dw_store_tile(t, (gf_ptr)(partials + (size_t)blk.split * n_params), acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
+    if (active) {
+        gf_ptr out = (gf_ptr)(partials + (size_t)blk.split * n_params);
+        if (arr1) dw_store_tile<1>(t, out, acc, t.n0, t.k0 + 32 * wk, lane);
+        else      dw_store_tile<2>(t, out, acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
+    }
 }
 
 // ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  Same scheme as 4a at a finer grain:
@@ -861,10 +889,13 @@ hipError_t bwd_set_attributes(int W, int ha) {
         hipError_t e = hipFuncSetAttribute(bwd_data_fn(W, b16 != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
-    if (e != hipSuccess) return e;
+    const void* bigs[4] = {reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 1>),
+                           reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 1>)};
+    hipError_t e = hipSuccess;
+    for (const void* fn : bigs) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwSmallLds);
 }
 
@@ -945,7 +976,7 @@ static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
     for (int n0 = 0; n0 < N; n0 += tn)
         for (int k0 = 0; k0 < Kvalid; k0 += tk) {
             DwTile t{};
-            t.gk = gk; t.wk = wk;
+            t.gk = is_big ? (N - n0 <= 128 ? 1 : 0) : gk; t.wk = wk;
             t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
             t.nseg = nseg;
             for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
@@ -998,22 +1029,47 @@ static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
     }
 }
 
-// per_kslice: one block per existing 64-wide k-slice of every tile (small kernel), else one block per tile
-// returns the number of non-empty splits: exactly the slots [0, that) of every tile's tensor are written by a launch
-static int make_blocks(std::vector<DwBlock>& blocks, const std::vector<DwTile>& tiles, int nsplit, int64_t P, int round_to, bool per_kslice) {
-    int64_t chunk = (P + nsplit - 1) / nsplit;
-    chunk = (chunk + round_to - 1) / round_to * round_to;
-    int used = 0;
-    for (int s = 0; s < nsplit; ++s) {
-        const int64_t pb = (int64_t)s * chunk, pe = std::min<int64_t>(P, pb + chunk);
-        if (pb >= pe) continue;
-        ++used;
-        for (int t = 0; t < (int)tiles.size(); ++t) {
-            const int nks = per_kslice ? std::min(4, (tiles[t].K - tiles[t].k0 + 63) / 64) : 1;
-            for (int ks = 0; ks < nks; ++ks) { DwBlock b; b.tile = t; b.split = s; b.kslice = ks; b.pb = pb; b.pe = pe; blocks.push_back(b); }
+// blocks of a launch: tile t contributes t.nsplit blocks, each with an equal share of the points (rounded to whole LDS
+// stages).  Slots [0, used splits of its tile) of a tensor's partials are exactly the ones a launch writes.
+static void make_blocks(std::vector<DwBlock>& blocks, std::vector<DwTile>& tiles, int64_t P, int round_to, int only_arr = -1) {
+    const size_t first = blocks.size();
+    for (int t = 0; t < (int)tiles.size(); ++t) {
+        if (only_arr >= 0 && tiles[t].gk != only_arr) continue;
+        const int nsplit = std::max(1, tiles[t].nsplit);
+        int64_t chunk = (P + nsplit - 1) / nsplit;
+        chunk = (chunk + round_to - 1) / round_to * round_to;
+        int used = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            const int64_t pb = (int64_t)s * chunk, pe = std::min<int64_t>(P, pb + chunk);
+            if (pb >= pe) continue;
+            DwBlock b; b.tile = t; b.split = used++; b.kslice = 0; b.pad_ = 0; b.pb = pb; b.pe = pe;
+            blocks.push_back(b);
         }
+        tiles[t].nsplit = used;
     }
-    return used;
+    // longest blocks first: the hardware dispatches in index order
+    std::stable_sort(blocks.begin() + first, blocks.end(), [](const DwBlock& a, const DwBlock& b) { return (a.pe - a.pb) > (b.pe - b.pb); });
+}
+
+// Split counts of the big tiles: one block per CU in total, points shared out so that every block takes about the same
+// time.  A 1 x 8 tile (N <= 128) issues half the MFMAs per stage of a 2 x 4 tile, so it gets about half the splits.
+static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, int max_split) {
+    if (tiles.empty()) return;
+    auto cost = [](const DwTile& t) { return t.gk == 1 ? 0.55 : 1.0; };
+    double total = 0;
+    for (const DwTile& t : tiles) total += cost(t);
+    int cap = max_split;
+    while (cap > 1 && P / cap < 512) --cap;                  // at least 512 points per block
+    int used = 0;
+    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(n_cu * cost(t) / total))); used += t.nsplit; }
+    // hand the remaining CUs to the tiles whose blocks are longest
+    while (used < n_cu) {
+        DwTile* best = nullptr;
+        for (DwTile& t : tiles)
+            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
+        if (!best) break;
+        ++best->nsplit; ++used;
+    }
 }
 
 extern "C" {
@@ -1055,30 +1111,34 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         else BHIP(hipEventCreateWithFlags(&B.uploaded, hipEventDisableTiming));
         B.tiles.clear(); B.tiles_small.clear(); B.blocks.clear(); B.blocks_small.clear(); B.segs.clear();
         build_dw_jobs(c, L, q, P, B.tiles, B.tiles_small);
-        // split counts: every block of a kernel gets the same number of points; big tiles ~1 block per CU in total,
-        // small jobs a finer split (their blocks are short and run several per CU)
+        // split counts: big tiles ~1 block per CU in total, balanced by per-tile cost; small jobs a finer split (their
+        // blocks are short and run several per CU)
         const int kMaxSplit = 64;
-        int ns_big = std::max(1, (int)(m->n_cu / std::max<size_t>(1, B.tiles.size())));
-        ns_big = std::min(ns_big, kMaxSplit);
-        while (ns_big > 1 && P / ns_big < 512) --ns_big;
+        balance_big_splits(B.tiles, m->n_cu, P, kMaxSplit);
         int ns_small = kDwSlots;
         while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
-        B.ns_big = make_blocks(B.blocks, B.tiles, ns_big, P, kDwRows, false);
-        B.ns_small = make_blocks(B.blocks_small, B.tiles_small, ns_small, P, kDwRows, false);
+        for (DwTile& t : B.tiles_small) t.nsplit = ns_small;
+        make_blocks(B.blocks, B.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
+        B.n_blocks_wide = (int)B.blocks.size();
+        make_blocks(B.blocks, B.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
+        make_blocks(B.blocks_small, B.tiles_small, P, kDwRows);
         if ((int)B.tiles.size() > kMaxDwTiles || (int)B.tiles_small.size() > kMaxDwTiles || (int)B.blocks.size() > kMaxDwBlocks ||
             (int)B.blocks_small.size() > kMaxDwBlocks)
             return bfail(CFNERF_E_UNSUPPORTED, "weight-gradient plan exceeds the descriptor capacity (%zu/%zu tiles, %zu/%zu blocks)",
                          B.tiles.size(), B.tiles_small.size(), B.blocks.size(), B.blocks_small.size());
-        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  A launch writes every slot below
-        // its tensor's count, so the partial buffer never needs clearing.
+        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  A tensor fed by a big AND a small
+        // tile (skip layer, views layer) is reduced over the larger count: the slots its other tile never writes must
+        // read as zero, so the partial buffer is cleared HERE, when the plan is (re)built - never on the steady path,
+        // where every launch rewrites exactly the slots it wrote before.
+        BHIP(hipMemsetAsync(q.partials, 0, (size_t)kDwSlots * n_params * sizeof(float), st));
         for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; B.segs.push_back(r); }
-        auto mark = [&](const std::vector<DwTile>& tv, int ns) {
+        auto mark = [&](const std::vector<DwTile>& tv) {
             for (const DwTile& t : tv)
                 for (int g = 0; g < t.nseg; ++g)
                     for (RedSeg& r : B.segs)
-                        if (r.begin == t.seg_dst[g]) r.nsplit = std::max(r.nsplit, ns);
+                        if (r.begin == t.seg_dst[g]) r.nsplit = std::max(r.nsplit, t.nsplit);
         };
-        mark(B.tiles, B.ns_big); mark(B.tiles_small, B.ns_small);
+        mark(B.tiles); mark(B.tiles_small);
         if (B.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
         auto up = [&](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
         BHIP(up(q.tiles, B.tiles.data(), B.tiles.size() * sizeof(DwTile)));
@@ -1116,15 +1176,31 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
 
     // ---- 3. weight gradients + reductions
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
-    if (!B.blocks.empty()) {
+    // the 1 x 8 tiles (N <= 128: a handful of blocks) run on the model's side stream NEXT TO the 2 x 4 launch: the split
+    // balance hands them the CUs the 2 x 4 launch leaves free (fork / join with events: no host synchronisation)
+    const int n_wide = B.n_blocks_wide, n_narrow = (int)B.blocks.size() - n_wide;
+    if (n_narrow > 0) {
+        BHIP(hipEventRecord(m->ev_fork, st));
+        BHIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
         if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)B.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
-                               q.tiles, q.blocks, q.partials, n_params, q.zeros);
+            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
+                               q.tiles, q.blocks + n_wide, q.partials, n_params);
         else
-            hipLaunchKernelGGL(dw_big_kernel<PREC_F32>, dim3((unsigned)B.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
-                               q.tiles, q.blocks, q.partials, n_params, q.zeros);
+            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
+                               q.tiles, q.blocks + n_wide, q.partials, n_params);
+        BHIP(hipGetLastError());
+        BHIP(hipEventRecord(m->ev_join, m->side));
+    }
+    if (n_wide > 0) {
+        if (m->precision == PREC_BF16X3)
+            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 0>), dim3((unsigned)n_wide), dim3(kDwThreads), kDwBigLds, st,
+                               q.tiles, q.blocks, q.partials, n_params);
+        else
+            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 0>), dim3((unsigned)n_wide), dim3(kDwThreads), kDwBigLds, st,
+                               q.tiles, q.blocks, q.partials, n_params);
         BHIP(hipGetLastError());
     }
+    if (n_narrow > 0) BHIP(hipStreamWaitEvent(st, m->ev_join, 0));
     if (!B.blocks_small.empty()) {
         hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
                            q.tiles_small, q.blocks_small, q.partials, n_params, q.zeros);

@@ -74,9 +74,9 @@ class Trainer:
         self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
         self.world, self.group, self.start = int(world_size), group, int(start)
         self.rank = 0
-        if self.world > 1 or self.force_allreduce:
-            import torch.distributed as dist
-            self.rank = dist.get_rank(group)
+        import torch.distributed as dist
+        if (self.world > 1 or self.force_allreduce) and dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank(group)       # (world_size > 1 without a process group: shard semantics only, see forward_backward)
         n = self.net.n_params
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)

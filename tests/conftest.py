@@ -25,6 +25,14 @@ if os.path.exists("/dev/kfd"):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # never test a stale library: rebuild in-tree when a source is newer than libcfnerf_hip.so (no-op otherwise)
+    import importlib.util
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        spec = importlib.util.spec_from_file_location("cfnerf_build", os.path.join(ROOT, "cf-nerf_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
 
 
 @pytest.fixture(scope="session")

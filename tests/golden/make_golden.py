@@ -423,6 +423,11 @@ def main():
     g15 = dict(seed=63, netwidth=64, K=4, H=H, W=W, focal=focal, rays=rays_t, target=target, beta1=beta1, lrate=args.lrate,
                lrate_decay=args.lrate_decay, n_steps=3)
     import math
+    # tensors whose per-step gradients are kept, so that the fused Adam kernel can be driven with the reference's own
+    # gradients (the end-to-end trajectory is chaotic: Adam's first step is lr * sign(g))
+    G15_KEYS = ("pts_linears.0.weight", "pts_linears.5.weight", "pts_linears.5.bias", "h_rgb_linear.weight",
+                "flows_rgb.amor_d.weight", "flows_alpha.amor_b.bias", "alpha_std", "rgb_mean")
+    g15["adam_keys"] = np.array(G15_KEYS)
     for step in range(3):
         t_rand = torch.tensor(rng15.uniform(0, 1, (n, 128)), dtype=torch.float32)
         ea = torch.tensor(rng15.standard_normal((4, 1)), dtype=torch.float32)
@@ -439,7 +444,14 @@ def main():
         loss = loss_nll + beta1 * extras["loss_entropy"].mean()
         optimizer.zero_grad()                                                               # RUN:1065-1067
         loss.backward()
+        named = {k[len("module."):]: v for k, v in model.named_parameters()}
+        for k in G15_KEYS:                                                                  # what optimizer.step() is fed ...
+            g15[f"g{step}." + k] = named[k].grad.clone()
+            if step == 0:
+                g15["p0." + k] = named[k].detach().clone()
         optimizer.step()
+        for k in G15_KEYS:                                                                  # ... and what it makes of it
+            g15[f"p{step + 1}." + k] = named[k].detach().clone()
         decay_rate = 0.1                                                                    # RUN:1073-1077
         decay_steps = args.lrate_decay * 1000
         new_lrate = args.lrate * (decay_rate ** (global_step / decay_steps))

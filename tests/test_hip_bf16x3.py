@@ -75,7 +75,7 @@ def test_train_step_with_bf16x3_forward_matches_reference_gradients(golden):
     """Forward and backward-data in bf16x3, weight-gradient GEMMs in fp32: the gradients still meet the reference within
     the train tolerances."""
     from cfnerf_amd import train as TR
-    from test_hip_train import grad_close
+    from test_hip_train import grad_close, mask_corrected
     g = golden("g57_render_w64_ndc")
     cfg = O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]))
     _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]))
@@ -86,9 +86,12 @@ def test_train_step_with_bf16x3_forward_matches_reference_gradients(golden):
     grad = tr.forward_backward(int(g["H"]), int(g["W"]), float(g["focal"]), T(g["rays"]).to(DEV), T(g["target"]).to(DEV),
                                t_rand=T(g["t_rand"]).to(DEV), eps=eps)
     close(tr.scalars[0].cpu(), g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    rays = T(g["rays"])
+    packed = O.pack_rays(int(g["H"]), int(g["W"]), float(g["focal"]), rays[0], rays[1], True, 0., 1.)
+    corr, _ = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
     for key, (off, cnt) in net.layout.items():
         if ("grad." + key) in g:
-            grad_close(grad[off:off + cnt].cpu().numpy().reshape(g["grad." + key].shape), g["grad." + key], "grad " + key)
+            grad_close(grad[off:off + cnt].cpu().numpy().reshape(g["grad." + key].shape), g["grad." + key] + corr[key], "grad " + key)
 
 
 def test_bf16x3_accuracy_class_vs_fp64():

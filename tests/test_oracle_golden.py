@@ -291,6 +291,21 @@ def test_three_optimizer_steps(golden):
             assert (d > 3e-7).mean() <= 0.02, f"{k}: {(d > 3e-7).mean():.3%} entries differ"
 
 
+def test_adam_on_the_references_own_gradients(golden):
+    """G15: the oracle's adam_step fed with the gradients the reference's optimiser saw lands on its parameters after
+    each of the three steps (pure elementwise arithmetic: tight)."""
+    g = golden("g15_three_steps")
+    keys = [str(k) for k in g["adam_keys"]]
+    params = {k: T(g["p0." + k]).clone() for k in keys}
+    state, lr = {}, float(g["lrate"])
+    for step in range(3):
+        grads = {k: T(g[f"g{step}." + k]) for k in keys}
+        params = O.adam_step(params, grads, state, step + 1, lr)
+        for k in keys:
+            close(params[k], g[f"p{step + 1}." + k], atol=2e-9, rtol=1e-6, what=f"step {step} {k}")
+        lr = float(g[f"lr_after{step}"])
+
+
 def test_train_step_k16(golden):
     """G16: loss and every gradient at K = 16 latent samples (BASELINE config 4's count)."""
     g = golden("g16_train_k16")
