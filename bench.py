@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X-native CF-NeRF ray-batch hot path.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C1|W512]
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch of synthetic fern-shaped rays at
-BASELINE.json configs[1]: N_rand = 1024 rays per GPU, S = 128 samples (the reference's hard-coded
-table, single pass - it has no fine network), K = 4 latent samples, W = 256, D = 8.
-  --mode train (default when the backward is built): forward + KDE-NLL loss + backward + Adam
-  --mode eval : fused forward render only
-Rays are sharded across ranks (weak scaling: N_rand per GPU is fixed); the only exchange is one
-RCCL all-reduce of the flat gradient per train step.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic rays of a BASELINE.json config:
+  C2  (default at N = 1, the config the metric is quoted on)  N_rand 1024, K 4, W 256, fern-shaped NDC rays - train step
+  C4  (default at N > 1)  N_rand 1024 per GPU (8192 over 8), K 16 - train step, rays sharded, ONE all-reduce per step
+  C3  N_rand 4096, K 8, africa-like (no NDC, near 1.2 / far 8) - train step
+  C5  800 x 800 full-image eval, K 32, white background, rows tiled across ranks, fused uncertainty maps - eval
+  C1  N_rand 256, K 1 - forward only (the reference's K = 1 train loss is NaN)
+  W512  the authors' recipe (train_NF.sh): W 512, h_alpha 64, K 32, N_rand 512 - train step ("stress row" of SURVEY 8d)
+S = 128 samples always (the reference's hard-coded table; single pass - it has no fine network).
+  --mode train: forward + KDE-NLL loss + backward + Adam;  --mode eval: fused forward render only.
+Rays are sharded across ranks (weak scaling: rays per GPU fixed); the only exchange is one RCCL all-reduce of the flat
+gradient per train step.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -24,7 +29,18 @@ import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
-N_RAND, S, K, W, D = 1024, 128, 4, 256, 8
+S, D = 128, 8
+
+CONFIGS = {
+    # name: rays per GPU, K, width, h_alpha, mode, scene
+    "C1": dict(n=256, K=1, W=256, ha=32, mode="eval", scene="fern", what="LLFF-fern-shaped NDC rays, forward only (K=1)"),
+    "C2": dict(n=1024, K=4, W=256, ha=32, mode="train", scene="fern", what="LLFF-fern-shaped NDC rays"),
+    "C3": dict(n=4096, K=8, W=256, ha=32, mode="train", scene="africa", what="africa-like rays (no NDC, near 1.2 / far 8, 512x512, f=600)"),
+    "C4": dict(n=1024, K=16, W=256, ha=32, mode="train", scene="fern", what="LLFF-fern-shaped NDC rays, 1024 rays per GPU (8192 over 8 GPUs)"),
+    "C5": dict(n=None, K=32, W=256, ha=32, mode="eval", scene="blender", what="800x800 full-image eval (Blender intrinsics, near 2 / far 6, white background, "
+                                                                               "no NDC), rows tiled across ranks, fused K-statistics (uncertainty maps)"),
+    "W512": dict(n=512, K=32, W=512, ha=64, mode="train", scene="fern", what="the authors' recipe (train_NF.sh): W=512, h_alpha=64, K=32, N_rand=512"),
+}
 
 
 def gemm_flops_per_point(W=256, ha=32, hr=64, ic=63, icv=27, F=4):
@@ -35,36 +51,54 @@ def gemm_flops_per_point(W=256, ha=32, hr=64, ic=63, icv=27, F=4):
     return 2 * macs
 
 
-def fern_rays(rng, n, H=378, W=504, focal=407.5658):
-    """Fern-shaped synthetic rays: LLFF fern at factor 8, near-identity pose, n random pixels."""
+def synth_rays(rng, n, H, Wd, focal):
+    """n random pixels of a near-identity pose."""
     c2w = np.eye(4, dtype=np.float32)[:3]
     c2w[:, 3] = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
-    pix = rng.choice(H * W, size=n, replace=False)
-    j, i = np.divmod(pix, W)
-    dirs = np.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i, dtype=np.float64)], -1)
+    pix = rng.choice(H * Wd, size=n, replace=False)
+    j, i = np.divmod(pix, Wd)
+    dirs = np.stack([(i - Wd * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i, dtype=np.float64)], -1)
     rays_d = (dirs[:, None, :] * c2w[:3, :3]).sum(-1).astype(np.float32)
     rays_o = np.broadcast_to(c2w[:3, 3], rays_d.shape).astype(np.float32)
-    return torch.tensor(np.stack([rays_o, rays_d], 0)), (H, W, focal)
+    return torch.tensor(np.stack([rays_o, rays_d], 0))
 
 
-def synth_batch(rank, n, device):
-    rng = np.random.default_rng(1000 + rank)
-    rays, (H, Wd, focal) = fern_rays(rng, n)
-    target = torch.tensor(rng.uniform(0, 1, (n, 3)), dtype=torch.float32)
-    return rays.to(device), target.to(device), (H, Wd, focal)
+def fern_rays(rng, n, H=378, W=504, focal=407.5658):
+    return synth_rays(rng, n, H, W, focal), (H, W, focal)
 
 
-def cpu_baseline(mode, budget_s=30.0):
+SCENES = {
+    "fern": dict(H=378, W=504, focal=407.5658, ndc=True, near=0., far=1., white_bkgd=False),
+    "africa": dict(H=512, W=512, focal=600.0, ndc=False, near=1.2, far=8.0, white_bkgd=False),
+    "blender": dict(H=800, W=800, focal=1111.1, ndc=False, near=2.0, far=6.0, white_bkgd=True),
+}
+
+
+def blender_pose(theta=30., phi=-30., radius=4.):
+    """pose_spherical of the Blender loader (load_blender.py:29-34)."""
+    t = np.eye(4); t[2, 3] = radius
+    p = phi / 180. * np.pi
+    rp = np.array([[1, 0, 0, 0], [0, np.cos(p), -np.sin(p), 0], [0, np.sin(p), np.cos(p), 0], [0, 0, 0, 1.]])
+    th = theta / 180. * np.pi
+    rt = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1.]])
+    c2w = rt @ rp @ t
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1.]]) @ c2w
+    return torch.tensor(c2w[:3, :4], dtype=torch.float32)
+
+
+def cpu_baseline(mode, cfg, budget_s=30.0):
     """The CPU oracle (op-for-op PyTorch-CPU restatement of the reference, oracle/) timed on this box's
     host cores on a bounded sample of the same workload.  The thread count is swept (all usable
     cores is NOT the fastest for these GEMM sizes) and the best setting is reported with its count."""
     from oracle import cfnerf_oracle as O      # the ONLY use of oracle/ in this file: the checker timed as the CPU baseline
-    n_rays = N_RAND                              # the full per-GPU workload of one step
-    cfg = O.OracleCfg(netwidth=W, K_samples=K)
-    p = O.make_params(cfg, 0)
+    K, W = cfg["K"], cfg["W"]
+    n_rays = min(cfg["n"] or 1024, 1024)        # bounded sample: at most 1024 rays of the per-GPU workload
+    sc = SCENES[cfg["scene"]]
+    ocfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=cfg["ha"])
+    p = O.make_params(ocfg, 0)
     rng = np.random.default_rng(5)
-    rays, (H, Wd, focal) = fern_rays(rng, n_rays)
-    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    rays = synth_rays(rng, n_rays, sc["H"], sc["W"], sc["focal"])
+    packed = O.pack_rays(sc["H"], sc["W"], sc["focal"], rays[0], rays[1], sc["ndc"], sc["near"], sc["far"])
     t_rand = torch.rand(n_rays, S)
     ea, er = torch.randn(K, 1), torch.randn(K, 3)
     target = torch.rand(n_rays, 3)
@@ -76,11 +110,11 @@ def cpu_baseline(mode, budget_s=30.0):
     def one():
         t0 = time.perf_counter()
         if mode == "train":
-            scal, grads, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, 0.01)
+            scal, grads, _ = O.train_step(p, packed, target, ocfg, ea, er, t_rand, 0.01, white_bkgd=sc["white_bkgd"])
             O.adam_step({k: v.clone() for k, v in p.items()}, grads, {}, 1, 5e-4)
         else:
             with torch.no_grad():
-                O.render_rays(p, packed, cfg, ea, er, False)
+                O.render_rays(p, packed, ocfg, ea, er, False, white_bkgd=sc["white_bkgd"])
         return time.perf_counter() - t0
 
     t_start = time.perf_counter()
@@ -106,14 +140,96 @@ def cpu_baseline(mode, budget_s=30.0):
     return out
 
 
+class Workload:
+    """One config on this rank: model, synthetic inputs resident in HBM, step()."""
+
+    def __init__(self, name, mode, rank, world, dev, precision="fp32", force_dist=False, hierarchical=0):
+        import contextlib
+        import cfnerf_amd
+        from cfnerf_amd import _lib as L
+        self.name, self.cfg = name, CONFIGS[name]
+        cfg = self.cfg
+        self.mode = mode or cfg["mode"]
+        self.K, self.W, self.world, self.rank, self.dev = cfg["K"], cfg["W"], world, rank, dev
+        sc = self.sc = SCENES[cfg["scene"]]
+        torch.manual_seed(0)                    # same random-init weights on every rank (nn.Linear-style init of the product)
+        with contextlib.redirect_stdout(sys.stderr):            # create_nerf prints the reference's "No reloading" notice
+            kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(
+                netwidth=self.W, netdepth=D, K_samples=self.K, h_alpha_size=cfg["ha"], device=dev, no_ndc=not sc["ndc"],
+                white_bkgd=sc["white_bkgd"], dataset_type="llff" if sc["ndc"] else "blender"))
+        self.kw_train, self.kw_test = kw_train, kw_test
+        self.net = kw_train["network_fn"].module
+        self.lib = L.lib()
+        self.lib.cfnerf_timing_enable(self.net.handle, 1)
+        self.net.set_precision(precision)
+        self.cfnerf = cfnerf_amd
+        self.g = torch.Generator(device=dev).manual_seed(1234)  # explicit latents: same on every rank (Trainer enforces it otherwise)
+        H, Wd, focal = sc["H"], sc["W"], sc["focal"]
+        if name == "C5":
+            from cfnerf_amd import evaluate as EV
+            self.EV = EV
+            self.c2w = blender_pose()
+            self.r0, self.r1 = EV.row_shard(H, rank, world)
+            self.n = (self.r1 - self.r0) * Wd
+        else:
+            self.n = cfg["n"]
+            rng = np.random.default_rng(1000 + rank)
+            self.rays = synth_rays(rng, self.n, H, Wd, focal).to(dev)
+            self.target = torch.tensor(rng.uniform(0, 1, (self.n, 3)), dtype=torch.float32).to(dev)
+        if self.mode == "train":
+            from cfnerf_amd import train as T
+            self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist)
+        self.hier = hierarchical
+
+    def step(self):
+        sc, dev = self.sc, self.dev
+        H, Wd, focal = sc["H"], sc["W"], sc["focal"]
+        if self.name == "C5":
+            with torch.no_grad():
+                return self.EV.render_uncertainty(H, Wd, focal, self.c2w, self.net, near=sc["near"], far=sc["far"], ndc=False,
+                                                  white_bkgd=True, rows=(self.r0, self.r1))
+        if self.mode == "train":
+            t_rand = torch.rand(self.n, S, device=dev)
+            eps = torch.randn(self.K, 4, device=dev, generator=self.g)
+            return self.trainer.step(H, Wd, focal, self.rays, self.target, t_rand=t_rand, eps=eps, near=sc["near"], far=sc["far"],
+                                     ndc=sc["ndc"], white_bkgd=sc["white_bkgd"])
+        with torch.no_grad():
+            return self.cfnerf.render(H, Wd, focal, rays=self.rays, near=sc["near"], far=sc["far"], **self.kw_test)
+
+    def kernel_ms(self):
+        names = (("fwd", 0),) + ((("bwd_tail", 1), ("bwd_data", 2), ("bwd_dw", 3), ("adam", 4)) if self.mode == "train" else ())
+        return {k: self.lib.cfnerf_timing_last_ms(self.net.handle, i) for k, i in names}
+
+    def describe(self, precision):
+        c = self.cfg
+        n = f"N_rand={self.n}/GPU" if self.name != "C5" else f"{self.n} rays/GPU (rows {self.r0}..{self.r1} of 800)"
+        return (f"{self.name}: {c['what']}; {n}, S={S} (reference table, single pass), K={self.K}, W={self.W}, D={D}, h_alpha={c['ha']}, "
+                f"mode={self.mode}, precision={precision}")
+
+    def fwd_flops(self):
+        return gemm_flops_per_point(self.W, self.cfg["ha"]) * self.n * S
+
+
+def timed(wl, steps, warmup, sync):
+    for _ in range(warmup):
+        wl.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: C2 on one GPU, C4 (K=16, 1024 rays/GPU) on several")
     ap.add_argument("--mode", choices=["train", "eval"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement reported next to the fp32 line")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements reported next to the main line (bf16x3, W512 stress row)")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = exact-fp32 MFMA (default, the measured parity path); bf16x3 = opt-in split-bf16 MFMA mode")
     args = ap.parse_args()
@@ -126,6 +242,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("CFNERF_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (tests)
+    dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -134,104 +251,80 @@ def main():
             os.environ.update(RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
-    import cfnerf_amd
-    from cfnerf_amd import _lib as L
-    try:
-        from cfnerf_amd import train as T
-        have_train = T.backward_available()
-    except Exception:
-        T, have_train = None, False
-    mode = args.mode or ("train" if have_train else "eval")
-    if mode == "train" and not have_train:
-        raise SystemExit("train mode requested but the backward kernels are not built")
-
-    torch.manual_seed(0)                        # same random-init weights on every rank (nn.Linear-style init of the product)
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):                # create_nerf prints the reference's "No reloading" notice
-        kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=W, netdepth=D, K_samples=K, device=dev))
-    model = kw_train["network_fn"]
-    net = model.module
-    rays, target, (H, Wd, focal) = synth_batch(rank, N_RAND, dev)
-    lib = L.lib()
-    lib.cfnerf_timing_enable(net.handle, 1)
-    net.set_precision(args.precision)
-    g = torch.Generator(device=dev).manual_seed(1234)           # same latent samples on every rank
-
-    if mode == "train":
-        trainer = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist)
-
-    def step():
-        t_rand = torch.rand(N_RAND, S, device=dev)
-        eps = torch.randn(K, 4, device=dev, generator=g)
-        if mode == "train":
-            return trainer.step(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps, **kw_train)
-        with torch.no_grad():
-            return cfnerf_amd.render(H, Wd, focal, rays=rays, **kw_test)
+    from cfnerf_amd import train as T
+    if not T.backward_available():
+        raise SystemExit("the backward kernels are not built")
+    name = args.config or ("C2" if world == 1 else "C4")
+    wl = Workload(name, args.mode, rank, world, dev, args.precision, force_dist)
+    mode = wl.mode
 
     def sync():
-        if world > 1 or force_dist:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    kern_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP-event duration of the dominant kernel (fused forward) on the launch stream
-    sync()
-    dt = time.perf_counter() - t0
-    # per-launch duration of the dominant kernel from the library's HIP events (last step; queried after the timed region)
-    fwd_ms = lib.cfnerf_timing_last_ms(net.handle, 0)
-    extra_ms = {}
-    if mode == "train":
-        for name, idx in (("bwd_tail", 1), ("bwd_data", 2), ("bwd_dw", 3), ("adam", 4)):
-            extra_ms[name] = lib.cfnerf_timing_last_ms(net.handle, idx)
-    if world > 1 or force_dist:
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    dt = max_over_ranks(timed(wl, args.steps, args.warmup, sync))
+    # per-launch duration of the dominant kernel from the library's HIP events on the launch stream (last step)
+    kms = wl.kernel_ms()
+    fwd_ms = kms["fwd"]
 
     # the opt-in split-bf16 mode, measured the same way right after (every rank runs it: the all-reduce is inside)
     alt = None
-    if args.precision == "fp32" and not args.no_alt:
-        net.set_precision("bf16x3")
-        for _ in range(min(3, args.warmup) or 1):
-            step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dta = time.perf_counter() - t1
-        alt_fwd_ms = lib.cfnerf_timing_last_ms(net.handle, 0)
-        if world > 1 or force_dist:
-            t = torch.tensor([dta], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dta = float(t.item())
-        net.set_precision("fp32")
+    if args.precision == "fp32" and not args.no_alt and name != "C5":
+        wl.net.set_precision("bf16x3")
+        dta = max_over_ranks(timed(wl, args.steps, min(3, args.warmup) or 1, sync))
+        alt_fwd_ms = wl.kernel_ms()["fwd"]
+        wl.net.set_precision("fp32")
         alt = {"precision": "bf16x3 (opt-in): fp32 operands carried as hi+lo bf16, product = hi*hi + hi*lo + lo*hi on "
                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward, backward-data and the large weight-gradient GEMMs; "
                             "held to the same parity tolerances (tests/test_hip_bf16x3.py)",
-               "value": N_RAND * world * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
-               "fwd_launch_ms": alt_fwd_ms}
+               "value": wl.n * world * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
+               "fwd_launch_ms": alt_fwd_ms, "fwd_fp32_equiv_tflops": wl.fwd_flops() / (alt_fwd_ms * 1e-3) / 1e12}
 
+    # SURVEY 8d "stress row": the authors' own recipe, next to the headline line (one GPU, default run only)
+    stress = None
+    if world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32":
+        del wl.trainer
+        wl.net.release_workspace()
+        ws = Workload("W512", "train", rank, world, dev, "fp32", False)
+        st_steps = max(5, min(20, args.steps))
+        dts = timed(ws, st_steps, 3, sync)
+        sk = ws.kernel_ms()
+        fl = ws.fwd_flops()
+        stress = {"workload": ws.describe("fp32"), "value": ws.n * st_steps / dts, "unit": "rays/s", "ms_per_step": dts / st_steps * 1e3,
+                  "kernel_ms": sk, "flops_per_ray_fwd": fl / ws.n,
+                  "roofline": {"bound": "mfma", "kernel": "fused_fwd_kernel<512,rays,train>", "achieved": fl / (sk["fwd"] * 1e-3) / 1e12,
+                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (sk["fwd"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF},
+                  "step_frac_of_peak": 3 * fl / (dts / st_steps) / 1e12 / FP32_MFMA_PEAK_TF}
+        ws.net.release_workspace()
+        del ws
+
+    out = None
     if rank == 0:
-        rays_per_s = N_RAND * world * args.steps / dt
-        fl = gemm_flops_per_point(W) * N_RAND * S          # forward GEMM FLOPs of one launch of the fused forward kernel
+        rays_per_s = wl.n * world * args.steps / dt
+        fl = wl.fwd_flops()                     # forward GEMM FLOPs of one launch of the fused forward kernel
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
-        traffic, mfma_busy = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tj = json.load(f)[mode]
-            traffic, mfma_busy = tj["hbm_bytes_per_launch"], tj.get("mfma_busy_frac")
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "kernel": f"fused_fwd_kernel<256,rays,{'train' if mode == 'train' else 'eval'}>",
+        traffic, mfma_busy, src = None, None, None
+        for prof in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", prof)) as f:
+                    tj = json.load(f)[f"{name}:{mode}" if prof.startswith("r02") else mode]
+                if prof.startswith("r01") and name != "C2":
+                    continue
+                traffic, mfma_busy, src = tj["hbm_bytes_per_launch"], tj.get("mfma_busy_frac"), prof
+                break
+            except Exception:
+                continue
+        roof = {"bound": "mfma", "kernel": f"fused_fwd_kernel<{wl.W},rays,{'train' if mode == 'train' else 'eval'}>",
                 "achieved": fl / (fwd_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": traffic,
-                "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.txt)",
+                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{src})" if src else None,
                 "mfma_busy_frac_pmc": mfma_busy, "launch_ms": fwd_ms, "flops_per_launch": fl}
         roof["frac"] = roof["achieved"] / roof["peak"]
         out = {
@@ -239,18 +332,20 @@ def main():
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16x3-split MFMA, f32 accumulate (opt-in mode)", "data": "synthetic",
-            "config": {"workload": f"LLFF-fern-shaped synthetic rays, N_rand={N_RAND}/GPU, S={S} (reference table, single pass), "
-                                   f"K={K}, W={W}, D={D}, NDC, mode={mode}, precision={args.precision}",
+            "config": {"workload": wl.describe(args.precision),
                        "parallelism": f"ray-sharded dp{world}" + (", 1 RCCL all-reduce of flat grads/step" if mode == "train" and world > 1 else "")},
             "roofline": roof,
         }
-        if extra_ms:
-            out["kernel_ms"] = dict(fwd=fwd_ms, **extra_ms)
+        if mode == "train":
+            out["kernel_ms"] = kms
+            out["step_frac_of_peak"] = 3 * fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF
         if alt is not None:
-            alt["fwd_fp32_equiv_tflops"] = fl / (alt["fwd_launch_ms"] * 1e-3) / 1e12
             out["alt_precision"] = alt
+        if stress is not None:
+            out["stress_w512"] = stress
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mode)
+            out["cpu_baseline"] = cpu_baseline(mode, wl.cfg)
+
     # the JSON line is the LAST thing on stdout: RCCL prints its version banner through libc's buffered stdout (it would
     # otherwise surface at process exit, after the line), so every rank flushes that before the final barrier
     def flush_c_stdio():
@@ -261,7 +356,7 @@ def main():
             pass
         sys.stdout.flush()
     flush_c_stdio()
-    if world > 1 or force_dist:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()

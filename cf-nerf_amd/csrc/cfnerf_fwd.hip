@@ -15,17 +15,27 @@
 
 namespace cfnerf {
 
+// Waves per workgroup of the fused forward.  W <= 256: 4 waves, two workgroups per CU (one's epilogues hide under the
+// other's MFMAs).  W = 512: the in-place LDS tile (132 KB) allows one workgroup per CU, and 64 x 512 outputs held in
+// registers until every wave has read the layer's input are 128 accumulator registers per lane with 4 waves - with the
+// weight ping-pong that overflows the 256 architectural VGPRs (the 4-wave build spilt ~700 registers to scratch and
+// shuffled thousands of values through AccVGPRs).  8 waves halve it: 2 n-tiles per wave like the W = 256 kernel, two
+// waves per SIMD, 256 registers each, no scratch.
+__host__ __device__ constexpr int fwd_waves(int W) { return W > 256 ? 8 : 4; }
+
 template <int W>
 struct FwdCfg {
+    static constexpr int NWV = fwd_waves(W);
+    static constexpr int NTHR = NWV * 64;
     static constexpr int NT = W / 32;                         // n tiles of a W-wide layer
-    static constexpr int NTW = (NT + kWaves - 1) / kWaves;    // per wave
-    static constexpr int NTV = (W / 64 + kWaves - 1) / kWaves;// views layer (W/2 wide)
+    static constexpr int NTW = (NT + NWV - 1) / NWV;          // per wave
+    static constexpr int NTV = (W / 64 + NWV - 1) / NWV;      // views layer (W/2 wide)
     static constexpr int LD = act_ld(W);
 };
 
 __host__ __device__ inline size_t fwd_lds_bytes(int W, int ha) {
-    // act[64][LD] | hs[64][ha+4] | rowinfo[65][4] (+pad) | gdir[32] | comp[kMaxK][8] | red[8]
-    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4) + 68 * 4 + 32 + kMaxK * 8 + 8);
+    // act[64][LD] | hs[64][ha+4] | rowinfo[65][4] (+pad) | gdir[32] | comp[kMaxK][8] | red[16]
+    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4) + 68 * 4 + 32 + kMaxK * 8 + 16);
 }
 
 __device__ __forceinline__ float zlin_f(float t, float nearv, float farv, bool lindisp) {
@@ -34,7 +44,7 @@ __device__ __forceinline__ float zlin_f(float t, float nearv, float farv, bool l
 }
 
 // positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
-template <int MODE, int LD, int PREC>
+template <int MODE, int LD, int PREC, int NTHR>
 __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, const float* __restrict__ x, int64_t p0,
                                             int rows_valid, int ic, int icv) {
     const int tid = threadIdx.x;
@@ -43,7 +53,7 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
         // cos channel (3 + 6f + d, 3 + 6f + 3 + d) from one argument reduction; pair 30 carries the identity channels and
         // the padding.  A wave holds one pair for 64 rows: no divergence.  8 items per thread instead of 16 sin-or-cos.
         const int nfreq = (ic - 3) / 6;
-        for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
+        for (int idx = tid; idx < kTileM * 32; idx += NTHR) {
             const int row = idx & 63, p = idx >> 6;
             const float* v = rowinfo + row * 4;
             float* dst = act + row * LD;
@@ -59,7 +69,7 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
             }
         }
     } else {
-        for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
+        for (int idx = tid; idx < kTileM * 64; idx += NTHR) {
             const int row = idx >> 6, c = idx & 63;
             float v = 0.f;
             if (c < ic && row < rows_valid) v = x[(p0 + row) * (int64_t)(ic + icv) + c];
@@ -76,10 +86,11 @@ extern "C" int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
 #endif
 
 template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
-__global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
+__global__ __launch_bounds__(FwdCfg<W>::NTHR, 2)
 void fused_fwd_kernel(const FwdArgs A) {
     using C = FwdCfg<W>;
     constexpr int LD = C::LD;
+    constexpr int kWv = C::NWV, kThr = C::NTHR;     // waves / threads of this width's workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const NetTab& T = *A.tab;
     const int HA = T.ha_sz, HR = T.hr_sz;
@@ -89,7 +100,7 @@ void fused_fwd_kernel(const FwdArgs A) {
     float* rowinfo = hs + kTileM * HLD;       // [65][4]: x y z zval
     float* gdir = rowinfo + 68 * 4;           // [32]
     float* comp = gdir + 32;                  // [kMaxK][8]: r g b depth acc T _ _
-    float* red = comp + kMaxK * 8;            // [8]
+    float* red = comp + kMaxK * 8;            // [16]
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* __restrict__ wp = A.wp;
@@ -181,10 +192,10 @@ void fused_fwd_kernel(const FwdArgs A) {
 
             CFN_MARK();                              // sampling done
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
-            encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
+            encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             if (A.st_enc != nullptr) {
                 __syncthreads();
-                for (int idx = tid; idx < kTileM * 64; idx += kThreads) {
+                for (int idx = tid; idx < kTileM * 64; idx += kThr) {
                     const int row = idx >> 6, c = idx & 63;
                     if (row < rows_valid) st_stream(A.st_enc + (p0 + row) * 64 + c, act_load<PREC>(act + row * LD + c));
                 }
@@ -196,22 +207,22 @@ void fused_fwd_kernel(const FwdArgs A) {
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
                 float bias[C::NTW];
-                load_bias<C::NTW>(T.trunk[l], wave, kWaves, wp, bias);
+                load_bias<C::NTW>(T.trunk[l], wave, kWv, wp, bias);
                 acc_init(acc, bias);
                 CFN_MARK();                          // MFMA phase of layer l starts
-                mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.trunk[l], wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(acc, T.trunk[l], wave, kWv, wp, wp16, act, LD);
                 CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
-                    encode_tile<MODE, LD, PREC>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
+                    encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
                     __syncthreads();
-                    mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.skipseg, wave, kWaves, wp, wp16, act, LD);
+                    mma_any<C::NTW, PREC, 2>(acc, T.skipseg, wave, kWv, wp, wp16, act, LD);
                 }
                 __syncthreads();
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.trunk[l], wave, kWaves, wp, act, LD, 0, st, W, rows_valid, mb);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.trunk[l], wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
                 CFN_MARK();                          // epilogue + barrier done
@@ -224,10 +235,10 @@ void fused_fwd_kernel(const FwdArgs A) {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
                 float biasF[C::NTW];
-                load_bias<C::NTW>(T.ft, wave, kWaves, wp, biasF);
+                load_bias<C::NTW>(T.ft, wave, kWv, wp, biasF);
                 acc_init(accF, biasF); acc_zero(accA);
-                mma_ksplit<PREC, (W > 256 ? 3 : 2)>(accA, T.ha, wave, kWaves, wp, wp16, act, LD);
-                mma_any<C::NTW, PREC, (W > 256 ? 3 : 2)>(accF, T.ft, wave, kWaves, wp, wp16, act, LD);
+                mma_ksplit<PREC, 2>(accA, T.ha, wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(accF, T.ft, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
                 {
                     const int lo = lane_id_opaque();
@@ -239,8 +250,8 @@ void fused_fwd_kernel(const FwdArgs A) {
                 }
                 __syncthreads();
                 {
-                    const int ntc = (int)T.ha.nt, nparts = kWaves / ntc;
-                    for (int idx = tid; idx < kTileM * HA; idx += kThreads) {
+                    const int ntc = (int)T.ha.nt, nparts = kWv / ntc;
+                    for (int idx = tid; idx < kTileM * HA; idx += kThr) {
                         const int row = idx / HA, c = idx - row * HA;
                         const float* pp = act + row * LD + 32 * (c >> 5) + (c & 31);     // wave w = part * ntc + n-tile
                         float v = pp[0];
@@ -251,7 +262,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     }
                 }
                 __syncthreads();
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN, true>(accF, T.ft, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN, true>(accF, T.ft, wave, kWv, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
             }
@@ -260,11 +271,11 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][C::NTV];
                 float bias[C::NTV];
-                load_bias<C::NTV>(T.vf, wave, kWaves, wp, bias);
+                load_bias<C::NTV>(T.vf, wave, kWv, wp, bias);
                 acc_init(acc, bias);
-                mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vf, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, 2>(acc, T.vf, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
-                for (int idx = tid; idx < kTileM * 32; idx += kThreads) {
+                for (int idx = tid; idx < kTileM * 32; idx += kThr) {
                     const int row = idx >> 5, c = idx & 31;
                     float v;
                     if (MODE == 0) v = gdir[c];
@@ -273,10 +284,10 @@ void fused_fwd_kernel(const FwdArgs A) {
                     if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
-                mma_any<C::NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.vd, wave, kWaves, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, 2>(acc, T.vd, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.vf, wave, kWaves, wp, act, LD, 0,
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.vf, wave, kWv, wp, act, LD, 0,
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
             }
@@ -285,11 +296,11 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][1];
                 float bias[1];
-                load_bias<1>(T.hr, wave, kWaves, wp, bias);
+                load_bias<1>(T.hr, wave, kWv, wp, bias);
                 acc_init(acc, bias);
-                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.hr, wave, kWaves, wp, wp16, act, LD);
+                mma_any<1, PREC, 2>(acc, T.hr, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, T.hr, wave, kWaves, wp, act, LD, W / 2,
+                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, T.hr, wave, kWv, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
@@ -299,9 +310,10 @@ void fused_fwd_kernel(const FwdArgs A) {
             {
                 f32x16 acc[2][1];
                 acc_zero(acc);
-                const bool is_rgb = wave < 3;
-                if (is_rgb) mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.fr, wave, kWaves, wp, wp16, act + W / 2, LD);
-                else        mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.fa, 0, kWaves, wp, wp16, hs, HLD);
+                const bool is_rgb = wave < 3;               // waves 0-2: the three rgb n-tiles; wave 3: alpha; others idle
+                const bool is_theta = wave < 4;
+                if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act + W / 2, LD);
+                else if (is_theta) mma_any<1, PREC, 2>(acc, T.fa, 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
                 const SubL s = is_rgb ? T.fr : T.fa;
                 const int nt = is_rgb ? wave : 0;
@@ -330,9 +342,11 @@ void fused_fwd_kernel(const FwdArgs A) {
                             if (M == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * kThetaAll, v); }
                         }
                 };
-                if (stash_mode == 0) theta_out(std::integral_constant<int, 0>{});
-                else if (stash_mode == 1) theta_out(std::integral_constant<int, 1>{});
-                else theta_out(std::integral_constant<int, 2>{});
+                if (is_theta) {
+                    if (stash_mode == 0) theta_out(std::integral_constant<int, 0>{});
+                    else if (stash_mode == 1) theta_out(std::integral_constant<int, 1>{});
+                    else theta_out(std::integral_constant<int, 2>{});
+                }
                 __syncthreads();
             }
             CFN_MARK();                              // theta done
@@ -361,7 +375,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                     const float dz = (s == S - 1) ? 1e1f : rowinfo[(row + 1) * 4 + 3] - zval;      // RUN:426-427
                     dist = dz * dnorm;                                                             // RUN:429
                 }
-                for (int k = wave; k < K; k += kWaves) {
+                for (int k = wave; k < K; k += kWv) {
                     const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
                     float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
                     float a = e[3] * a_std + a_mean;                                               // MOD:200/239
@@ -456,8 +470,13 @@ void fused_fwd_kernel(const FwdArgs A) {
         if (lane == 0) { red[wave * 2] = sr; red[wave * 2 + 1] = sa; }
         __syncthreads();
         if (tid == 0) {
-            A.ent_partials[blockIdx.x * 2 + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-            A.ent_partials[blockIdx.x * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+            float e0 = (red[0] + red[2]) + (red[4] + red[6]), e1 = (red[1] + red[3]) + (red[5] + red[7]);
+            if (kWv == 8) {
+                e0 += (red[8] + red[10]) + (red[12] + red[14]);
+                e1 += (red[9] + red[11]) + (red[13] + red[15]);
+            }
+            A.ent_partials[blockIdx.x * 2 + 0] = e0;
+            A.ent_partials[blockIdx.x * 2 + 1] = e1;
         }
     }
 }
@@ -734,9 +753,9 @@ __global__ void pack_kernel(const float* __restrict__ flat, float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // host launchers
-static int max_blocks_per_cu(const void* fn, size_t lds) {
+static int max_blocks_per_cu(const void* fn, size_t lds, int threads) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kThreads, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
@@ -748,7 +767,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, int
     int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(FwdCfg<W>::NTHR), lds, st, a);
     return hipGetLastError();
 }
 
@@ -786,7 +805,7 @@ static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
     for (const void* fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        per_cu = std::min(per_cu, max_blocks_per_cu(fn, lds));
+        per_cu = std::min(per_cu, max_blocks_per_cu(fn, lds, FwdCfg<W>::NTHR));
     }
 #ifdef CFN_FWD_MAX_PER_CU
     if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
