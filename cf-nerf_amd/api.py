@@ -598,11 +598,13 @@ def _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is
                               eps_alpha, eps_rgb, t_vals, u_fine):
     """EXTENSION, not in the reference: classic coarse+fine sampling through the single CF-NeRF network.
     Coarse pass on ``t_vals`` (default ``linspace(0,1,N_samples)``), ``cfnerf_sample_pdf`` on the K-mean coarse weights,
-    fine pass on the merged depths.  Forward only (no autograd).  Parity is pinned against the build's own CPU
-    restatement of nerf-pytorch's ``sample_pdf`` only - the reference has nothing to compare with."""
+    fine pass on the merged depths.  Under autograd the FINE pass is differentiated (explicit-depth STASH launch +
+    ``cfnerf_render_bwd``); the resampled depths are constants, as nerf-pytorch detaches ``z_samples``, and the coarse
+    pass only provides the sampling distribution (one network, one stash: its outputs ``rgb0`` / ``disp0`` / ``depth0``
+    are returned detached - ``train.Trainer.step_hierarchical`` adds a coarse loss term with a second stashed pass).
+    Parity is pinned against the build's own CPU restatement of nerf-pytorch's ``sample_pdf`` only - the reference has
+    nothing to compare with."""
     model = _unwrap(network_fn)
-    if torch.is_grad_enabled() and model.flat.requires_grad and is_train:
-        raise NotImplementedError("the hierarchical extension is forward-only; wrap the call in torch.no_grad()")
     dev = ray_batch.device
     rays = _f32c(ray_batch)
     N, K = rays.shape[0], model.K_samples
@@ -630,11 +632,16 @@ def _render_rays_hierarchical(ray_batch, network_fn, N_samples, N_importance, is
                                       N, S_, K, flags, L.ptr(rgb), L.ptr(disp), L.ptr(depth), None, L.ptr(wts), None, None, L.ptr(ent),
                                       L.stream()), "cfnerf_render_fwd")
         return rgb, disp, depth, wts, ent
-    rgb0, disp0, depth0, w0, _ = launch(S, None, True)
-    z_all = torch.empty(N, S + N_importance, device=dev)
-    L.check(lib.cfnerf_sample_pdf(L.ptr(rays), L.ptr(tv), L.ptr(tr), flags, L.ptr(w0), L.ptr(u), N, S, K, N_importance, L.ptr(z_all),
-                                  L.stream()), "cfnerf_sample_pdf")
-    rgb, disp, depth, _, ent = launch(S + N_importance, z_all, False)
+    with torch.no_grad():
+        rgb0, disp0, depth0, w0, _ = launch(S, None, True)
+        z_all = torch.empty(N, S + N_importance, device=dev)
+        L.check(lib.cfnerf_sample_pdf(L.ptr(rays), L.ptr(tv), L.ptr(tr), flags, L.ptr(w0), L.ptr(u), N, S, K, N_importance, L.ptr(z_all),
+                                      L.stream()), "cfnerf_sample_pdf")
+    if is_train and N > 0 and torch.is_grad_enabled() and model.flat.requires_grad:
+        rgb, disp, depth, ent, _raw, _pts = _RenderFn.apply(model.flat, model, rays, tv, None, eps, flags, False, z_all)
+        ent = ent.reshape(1)
+    else:
+        rgb, disp, depth, _, ent = launch(S + N_importance, z_all, False)
     ret = {'rgb_map': rgb, 'disp_map': disp, 'depth_map': depth, 'rgb0': rgb0, 'disp0': disp0, 'depth0': depth0, 'z_vals': z_all}
     if is_train:
         ret['loss_entropy'] = ent.reshape(1, 1, 1).expand(N * (S + N_importance), K, 1)

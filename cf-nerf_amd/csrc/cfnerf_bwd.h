@@ -52,20 +52,25 @@ struct RedSeg { uint32_t begin; int32_t nsplit; };
 // one workgroup of a weight-gradient launch: tile index, split slot and its point range
 struct DwBlock { int32_t tile, split, kslice, pad_; int64_t pb, pe; };
 
+// host copies of the weight-gradient descriptors of one plan; they must stay alive while their upload may be in flight
+struct DwHost {
+    std::vector<DwTile> tiles, tiles_small;
+    std::vector<DwBlock> blocks, blocks_small;
+    std::vector<RedSeg> segs;
+    hipEvent_t uploaded = nullptr;                        // recorded after this set's uploads
+};
+
 struct BwdPlan {
     bool built = false;
     int nb = 0, db_h = 0, db_feat = 0, db_v = 0, db_ha = 0, db_hr = 0, db_theta = 0;
     std::vector<BiasMap> bias_maps;
-    // host copies of the weight-gradient descriptors; they stay alive while their upload may be in flight
-    std::vector<DwTile> tiles, tiles_small;
-    std::vector<DwBlock> blocks, blocks_small;
-    std::vector<RedSeg> segs;
-    hipEvent_t uploaded = nullptr;                        // recorded after the descriptor uploads of the last rebuild
+    DwHost host[2];                                       // double-buffered: a rebuild never waits for the previous upload
+    int cur = 0;                                          // the set the device copies were made from
     uint64_t bind_serial = ~0ull;                         // Stash::bind_serial the descriptors were built for
     int n_blocks_wide = 0;                                // blocks[0, n_blocks_wide): 2 x 4 tiles; the rest: 1 x 8 tiles
     void release() {
-        if (uploaded) (void)hipEventDestroy(uploaded);
-        uploaded = nullptr; bind_serial = ~0ull;
+        for (DwHost& h : host) { if (h.uploaded) (void)hipEventDestroy(h.uploaded); h.uploaded = nullptr; }
+        bind_serial = ~0ull;
     }
 };
 

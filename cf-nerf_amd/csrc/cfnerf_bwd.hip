@@ -20,17 +20,23 @@
 namespace cfnerf {
 
 // ================================================================================================
-// 1. loss (RUN:1026-1050): one workgroup, deterministic.
-__global__ __launch_bounds__(1024)
-void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, const float* __restrict__ entropy,
-                 int64_t N, int K, float beta1, int64_t n_total, float* __restrict__ d_rgb, float* __restrict__ scalars) {
-    __shared__ double sh[2][1024];
+// 1. loss (RUN:1026-1050).  One thread per (ray, channel); the two sums (nll, squared error) are accumulated across
+//    workgroups as 64-bit FIXED-POINT integers (integer addition is associative: the result does not depend on the order
+//    the workgroups arrive in, so the step stays bit-reproducible) in the 16 bytes of `scalars`, which a one-thread
+//    finalize kernel then turns into [loss, loss_nll, mse, psnr].  (A single 1024-thread workgroup took 87 us at K = 16.)
+constexpr double kLossFix = 68719476736.0;      // 2^36: resolution 1.5e-11 per workgroup partial, |sum| < 3.3e7
+constexpr int kLossThreads = 256;
+__global__ __launch_bounds__(kLossThreads)
+void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, int64_t N, int K, int64_t n_total,
+                 float* __restrict__ d_rgb, long long* __restrict__ acc) {
+    __shared__ double sh[2][kLossThreads];
     const float invK = 1.f / (float)K;
     const float bw = powf(0.8f / (float)K, -1.f / 7.f);                 // torch.pow(0.8/n, tensor(-1/7))  RUN:1036
     const float c2pi = powf(2.f * 3.14159265358979323846f, -1.5f);      // RUN:1039
     const float gscale = 1.f / (3.f * (float)n_total);
     double nll = 0.0, mse = 0.0;
-    for (int64_t i = threadIdx.x; i < N * 3; i += blockDim.x) {
+    const int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
+    if (i < N * 3) {
         const float* x = rgb + i * K;                                   // [N,3,K]: (n,c) row of K values
         const float t = target[i];
         float mean = 0.f;
@@ -46,8 +52,8 @@ void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target
         float rsum = 0.f;
         for (int k = 0; k < K; ++k) { const float d = x[k] - t; rsum += expf(-(d * d) * inv2h2) * c2; }
         const float m = rsum * invK + 1e-05f;                           // RUN:1041
-        nll += -logf(m);                                                // RUN:1042
-        mse += (double)((mean - t) * (mean - t));                       // RUN:1028
+        nll = -logf(m);                                                 // RUN:1042
+        mse = (double)((mean - t) * (mean - t));                        // RUN:1028
         const float gcoef = gscale * invK / (m * H * H);
         for (int k = 0; k < K; ++k) {
             const float d = x[k] - t;
@@ -56,18 +62,29 @@ void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target
     }
     sh[0][threadIdx.x] = nll; sh[1][threadIdx.x] = mse;
     __syncthreads();
-    for (int d = 512; d >= 1; d >>= 1) {
+    for (int d = kLossThreads / 2; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) { sh[0][threadIdx.x] += sh[0][threadIdx.x + d]; sh[1][threadIdx.x] += sh[1][threadIdx.x + d]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double nllm = sh[0][0] / (3.0 * (double)n_total), msem = sh[1][0] / (3.0 * (double)n_total);
-        const float ent = entropy ? entropy[0] : 0.f;
-        scalars[0] = (float)nllm + (beta1 != 0.f ? beta1 * ent : 0.f);  // RUN:1047-1050
-        scalars[1] = (float)nllm;
-        scalars[2] = (float)msem;
-        scalars[3] = (float)(-10.0 * log(msem) / log(10.0));            // HLP:16
+        // a NaN / inf partial (K == 1, R4) must surface as NaN in the result, not as integer garbage: flag it in bit 62
+        const bool bad0 = !(fabs(sh[0][0]) < 1e8), bad1 = !(fabs(sh[1][0]) < 1e8);
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 0), bad0 ? (1ull << 62) : (unsigned long long)llrint(sh[0][0] * kLossFix));
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 1), bad1 ? (1ull << 62) : (unsigned long long)llrint(sh[1][0] * kLossFix));
     }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ entropy, float beta1, int64_t n_total, float* __restrict__ scalars) {
+    const long long a0 = reinterpret_cast<const long long*>(scalars)[0], a1 = reinterpret_cast<const long long*>(scalars)[1];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double s0 = (a0 >= (1ll << 61) || a0 < -(1ll << 61)) ? nan : (double)a0 / kLossFix;
+    const double s1 = (a1 >= (1ll << 61) || a1 < -(1ll << 61)) ? nan : (double)a1 / kLossFix;
+    const double nllm = s0 / (3.0 * (double)n_total), msem = s1 / (3.0 * (double)n_total);
+    const float ent = entropy ? entropy[0] : 0.f;
+    scalars[0] = (float)nllm + (beta1 != 0.f ? beta1 * ent : 0.f);      // RUN:1047-1050
+    scalars[1] = (float)nllm;
+    scalars[2] = (float)msem;
+    scalars[3] = (float)(-10.0 * log(msem) / log(10.0));                // HLP:16
 }
 
 // ================================================================================================
@@ -880,6 +897,9 @@ static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, 
 }
 
 constexpr size_t kDwBigLds = 4 * kDwRows * 256 * sizeof(float);
+// The 1 x 8 launch asks for more LDS than it uses (96 of 160 KB), so that two of its workgroups (122 VGPRs each) can
+// never be paired on one CU while another CU idles.
+constexpr size_t kDwNarrowLds = 96 * 1024;
 constexpr size_t kDwSmallLds = 2 * kDwRows * kDsMaxCols * sizeof(float);
 
 // Per-DEVICE set-up of the backward kernels of one width (called from cfnerf_model_create with that device current)
@@ -892,8 +912,8 @@ hipError_t bwd_set_attributes(int W, int ha) {
     const void* bigs[4] = {reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 1>),
                            reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 1>)};
     hipError_t e = hipSuccess;
-    for (const void* fn : bigs) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
+    for (int q = 0; q < 4; ++q) {
+        e = hipFuncSetAttribute(bigs[q], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((q & 1) ? kDwNarrowLds : kDwBigLds));
         if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwSmallLds);
@@ -1051,24 +1071,38 @@ static void make_blocks(std::vector<DwBlock>& blocks, std::vector<DwTile>& tiles
     std::stable_sort(blocks.begin() + first, blocks.end(), [](const DwBlock& a, const DwBlock& b) { return (a.pe - a.pb) > (b.pe - b.pb); });
 }
 
-// Split counts of the big tiles: one block per CU in total, points shared out so that every block takes about the same
-// time.  A 1 x 8 tile (N <= 128) issues half the MFMAs per stage of a 2 x 4 tile, so it gets about half the splits.
+// Split counts of the big tiles.  The 2 x 4 launch and (if the network has N <= 128 tiles) the 1 x 8 launch run side by
+// side, one workgroup per CU in total (their register budgets do not allow two on a CU).  Workgroups are dealt to the 8
+// XCDs round-robin, and where a launch's deal starts is not ours to choose, so an XCD may receive ceil(n / 8)
+// workgroups of EACH launch: the budgets are whole numbers of workgroups per XCD, 8 r for the 1 x 8 launch and
+// 8 (cu_per_xcd - r) for the 2 x 4 launch.  (Measured with 18 + 238 blocks: one XCD got 33, a 1 x 8 block waited for a
+// whole 2 x 4 block and the pair of launches took 2.05 ms instead of 1.1.)  r balances the two launches' block times;
+// a 1 x 8 block issues about 0.59 of a 2 x 4 block's work per point.
 static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, int max_split) {
     if (tiles.empty()) return;
-    auto cost = [](const DwTile& t) { return t.gk == 1 ? 0.55 : 1.0; };
-    double total = 0;
-    for (const DwTile& t : tiles) total += cost(t);
+    const int kXcd = 8, per_xcd = std::max(1, n_cu / kXcd);
     int cap = max_split;
     while (cap > 1 && P / cap < 512) --cap;                  // at least 512 points per block
-    int used = 0;
-    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(n_cu * cost(t) / total))); used += t.nsplit; }
-    // hand the remaining CUs to the tiles whose blocks are longest
-    while (used < n_cu) {
-        DwTile* best = nullptr;
+    int n_wide_t = 0, n_narrow_t = 0;
+    for (const DwTile& t : tiles) (t.gk == 1 ? n_narrow_t : n_wide_t)++;
+    int budget[2] = {kXcd * per_xcd, 0};                     // blocks of the 2 x 4 / 1 x 8 launch
+    if (n_narrow_t > 0 && n_wide_t > 0) {
+        int best_r = 1; double best = 1e30;
+        for (int r = 1; r < per_xcd; ++r) {
+            const double tn = 0.59 * n_narrow_t / (kXcd * r), tw = 1.0 * n_wide_t / (kXcd * (per_xcd - r));
+            if (std::max(tn, tw) < best) { best = std::max(tn, tw); best_r = r; }
+        }
+        budget[1] = kXcd * best_r; budget[0] = kXcd * (per_xcd - best_r);
+    } else if (n_narrow_t > 0) {
+        budget[1] = budget[0]; budget[0] = 0;
+    }
+    for (int arr = 0; arr < 2; ++arr) {
+        const int nt = arr ? n_narrow_t : n_wide_t;
+        if (nt == 0) continue;
+        const int base = std::max(1, std::min(cap, budget[arr] / nt));
+        int extra = (base < cap) ? std::max(0, budget[arr] - base * nt) : 0;
         for (DwTile& t : tiles)
-            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
-        if (!best) break;
-        ++best->nsplit; ++used;
+            if (t.gk == arr) { t.nsplit = base + (extra > 0 ? 1 : 0); if (extra > 0) --extra; }
     }
 }
 
@@ -1079,8 +1113,13 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
     if (N < 0 || K < 1 || n_total < N) return bfail(CFNERF_E_INVALID, "bad N/K/n_total");
     if (N == 0) return CFNERF_OK;
     if (!rgb_map || !target || !d_rgb_map || !scalars_out) return bfail(CFNERF_E_INVALID, "NULL argument");
-    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, rgb_map, target, entropy, N, K, beta1, n_total,
-                       d_rgb_map, scalars_out);
+    if (reinterpret_cast<uintptr_t>(scalars_out) % 8) return bfail(CFNERF_E_INVALID, "scalars_out must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    BHIP(hipMemsetAsync(scalars_out, 0, 4 * sizeof(float), st));        // the two 64-bit fixed-point accumulators live in these 16 bytes
+    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((N * 3 + kLossThreads - 1) / kLossThreads)), dim3(kLossThreads), 0, st, rgb_map, target,
+                       N, K, n_total, d_rgb_map, reinterpret_cast<long long*>(scalars_out));
+    BHIP(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, entropy, beta1, n_total, scalars_out);
     BHIP(hipGetLastError());
     return CFNERF_OK;
 }
@@ -1107,50 +1146,54 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     // ---- weight-gradient descriptors: they hold workspace pointers, so they are rebuilt (and uploaded, asynchronously,
     //      from host vectors that outlive the copy) only when the workspace binding moved - never on the steady path
     if (B.bind_serial != q.bind_serial) {
-        if (B.uploaded) BHIP(hipEventSynchronize(B.uploaded));       // the previous upload no longer reads the host vectors
-        else BHIP(hipEventCreateWithFlags(&B.uploaded, hipEventDisableTiming));
-        B.tiles.clear(); B.tiles_small.clear(); B.blocks.clear(); B.blocks_small.clear(); B.segs.clear();
-        build_dw_jobs(c, L, q, P, B.tiles, B.tiles_small);
+        B.cur ^= 1;
+        DwHost& Hs = B.host[B.cur];
+        if (Hs.uploaded) BHIP(hipEventSynchronize(Hs.uploaded));     // the upload made from THIS set two rebuilds ago is long done
+        else BHIP(hipEventCreateWithFlags(&Hs.uploaded, hipEventDisableTiming));
+        Hs.tiles.clear(); Hs.tiles_small.clear(); Hs.blocks.clear(); Hs.blocks_small.clear(); Hs.segs.clear();
+        build_dw_jobs(c, L, q, P, Hs.tiles, Hs.tiles_small);
         // split counts: big tiles ~1 block per CU in total, balanced by per-tile cost; small jobs a finer split (their
         // blocks are short and run several per CU)
         const int kMaxSplit = 64;
-        balance_big_splits(B.tiles, m->n_cu, P, kMaxSplit);
+        balance_big_splits(Hs.tiles, m->n_cu, P, kMaxSplit);
         int ns_small = kDwSlots;
         while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
-        for (DwTile& t : B.tiles_small) t.nsplit = ns_small;
-        make_blocks(B.blocks, B.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
-        B.n_blocks_wide = (int)B.blocks.size();
-        make_blocks(B.blocks, B.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
-        make_blocks(B.blocks_small, B.tiles_small, P, kDwRows);
-        if ((int)B.tiles.size() > kMaxDwTiles || (int)B.tiles_small.size() > kMaxDwTiles || (int)B.blocks.size() > kMaxDwBlocks ||
-            (int)B.blocks_small.size() > kMaxDwBlocks)
+        for (DwTile& t : Hs.tiles_small) t.nsplit = ns_small;
+        make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
+        B.n_blocks_wide = (int)Hs.blocks.size();
+        make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
+        make_blocks(Hs.blocks_small, Hs.tiles_small, P, kDwRows);
+        if ((int)Hs.tiles.size() > kMaxDwTiles || (int)Hs.tiles_small.size() > kMaxDwTiles || (int)Hs.blocks.size() > kMaxDwBlocks ||
+            (int)Hs.blocks_small.size() > kMaxDwBlocks)
             return bfail(CFNERF_E_UNSUPPORTED, "weight-gradient plan exceeds the descriptor capacity (%zu/%zu tiles, %zu/%zu blocks)",
-                         B.tiles.size(), B.tiles_small.size(), B.blocks.size(), B.blocks_small.size());
-        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  A tensor fed by a big AND a small
-        // tile (skip layer, views layer) is reduced over the larger count: the slots its other tile never writes must
-        // read as zero, so the partial buffer is cleared HERE, when the plan is (re)built - never on the steady path,
-        // where every launch rewrites exactly the slots it wrote before.
-        BHIP(hipMemsetAsync(q.partials, 0, (size_t)kDwSlots * n_params * sizeof(float), st));
-        for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; B.segs.push_back(r); }
+                         Hs.tiles.size(), Hs.tiles_small.size(), Hs.blocks.size(), Hs.blocks_small.size());
+        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  The tiles of one tensor may use
+        // different counts (a big and a small tile of the skip / views layer; tiles that got a spare CU): the tensor is
+        // reduced over the largest, so the slots some tile never writes must read as zero - they are cleared HERE, when
+        // the plan is (re)built, never on the steady path, where every launch rewrites exactly the slots it wrote before.
+        int ns_max = 1;
+        for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; Hs.segs.push_back(r); }
         auto mark = [&](const std::vector<DwTile>& tv) {
             for (const DwTile& t : tv)
                 for (int g = 0; g < t.nseg; ++g)
-                    for (RedSeg& r : B.segs)
-                        if (r.begin == t.seg_dst[g]) r.nsplit = std::max(r.nsplit, t.nsplit);
+                    for (RedSeg& r : Hs.segs)
+                        if (r.begin == t.seg_dst[g]) { r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit); }
         };
-        mark(B.tiles); mark(B.tiles_small);
-        if (B.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
+        mark(Hs.tiles); mark(Hs.tiles_small);
+        if (Hs.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
+        BHIP(hipMemsetAsync(q.partials, 0, (size_t)ns_max * n_params * sizeof(float), st));
         auto up = [&](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
-        BHIP(up(q.tiles, B.tiles.data(), B.tiles.size() * sizeof(DwTile)));
-        BHIP(up(q.tiles_small, B.tiles_small.data(), B.tiles_small.size() * sizeof(DwTile)));
-        BHIP(up(q.blocks, B.blocks.data(), B.blocks.size() * sizeof(DwBlock)));
-        BHIP(up(q.blocks_small, B.blocks_small.data(), B.blocks_small.size() * sizeof(DwBlock)));
-        BHIP(up(q.segs, B.segs.data(), B.segs.size() * sizeof(RedSeg)));
+        BHIP(up(q.tiles, Hs.tiles.data(), Hs.tiles.size() * sizeof(DwTile)));
+        BHIP(up(q.tiles_small, Hs.tiles_small.data(), Hs.tiles_small.size() * sizeof(DwTile)));
+        BHIP(up(q.blocks, Hs.blocks.data(), Hs.blocks.size() * sizeof(DwBlock)));
+        BHIP(up(q.blocks_small, Hs.blocks_small.data(), Hs.blocks_small.size() * sizeof(DwBlock)));
+        BHIP(up(q.segs, Hs.segs.data(), Hs.segs.size() * sizeof(RedSeg)));
         BHIP(up(q.bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap)));
         BHIP(hipMemsetAsync(q.zeros, 0, 256, st));
-        BHIP(hipEventRecord(B.uploaded, st));
+        BHIP(hipEventRecord(Hs.uploaded, st));
         B.bind_serial = q.bind_serial;
     }
+    const DwHost& Hc = B.host[B.cur];
 
     // ---- 1. tail
     TailArgs ta{};
@@ -1178,15 +1221,15 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
     // the 1 x 8 tiles (N <= 128: a handful of blocks) run on the model's side stream NEXT TO the 2 x 4 launch: the split
     // balance hands them the CUs the 2 x 4 launch leaves free (fork / join with events: no host synchronisation)
-    const int n_wide = B.n_blocks_wide, n_narrow = (int)B.blocks.size() - n_wide;
+    const int n_wide = B.n_blocks_wide, n_narrow = (int)Hc.blocks.size() - n_wide;
     if (n_narrow > 0) {
         BHIP(hipEventRecord(m->ev_fork, st));
         BHIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
         if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
+            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwNarrowLds, m->side,
                                q.tiles, q.blocks + n_wide, q.partials, n_params);
         else
-            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
+            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwNarrowLds, m->side,
                                q.tiles, q.blocks + n_wide, q.partials, n_params);
         BHIP(hipGetLastError());
         BHIP(hipEventRecord(m->ev_join, m->side));
@@ -1201,12 +1244,12 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         BHIP(hipGetLastError());
     }
     if (n_narrow > 0) BHIP(hipStreamWaitEvent(st, m->ev_join, 0));
-    if (!B.blocks_small.empty()) {
-        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)B.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
+    if (!Hc.blocks_small.empty()) {
+        hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)Hc.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
                            q.tiles_small, q.blocks_small, q.partials, n_params, q.zeros);
         BHIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, q.partials, q.segs, (int)B.segs.size(),
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(),
                        n_params, grad_flat);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,

@@ -275,7 +275,11 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     }
 }
 
+#ifdef CFN_EXP_NO_STASH_STORE
+__device__ __forceinline__ void st_stream(float* p, float v) { if (v == 1.2345e-30f) __builtin_nontemporal_store(v, p); }
+#else
 __device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
+#endif
 __device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
 
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
@@ -330,7 +334,9 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 act_store<PREC>(lp + rr * ld, v);
                 if (STASH == 1) st_stream(gp + rr * gld, v);
                 if (STASH == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * gld, v); }
+#ifndef CFN_EXP_NO_BITS
                 if (WANT_BITS) bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
+#endif
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there

@@ -190,6 +190,89 @@ class Trainer:
         net.mark_packed()
         return self.scalars
 
+    # ---- EXTENSION (not in the reference): coarse + fine sampling through the single network -----
+    def forward_backward_hierarchical(self, H, W, focal, rays, target, N_samples=64, N_importance=128, coarse_loss=True, t_rand=None,
+                                      u_fine=None, eps=None, near=0., far=1., ndc=True, lindisp=False, white_bkgd=False, perturb=1.,
+                                      **_ignored):
+        """Coarse pass on ``linspace(0,1,N_samples)`` -> ``cfnerf_sample_pdf`` (depths are constants, as nerf-pytorch
+        detaches ``z_samples``) -> fine pass on the merged N_samples + N_importance depths, loss and backward.  With
+        ``coarse_loss`` the coarse pass is run a second time WITH a stash and its own loss term is differentiated too
+        (nerf-pytorch adds img2mse(rgb0); here the same KDE-NLL as the fine term), so ``self.grad`` is the gradient of
+        loss_fine + loss_coarse.  Returns it; ``self.scalars`` holds the fine pass's [loss, nll, mse, psnr]."""
+        net, lib = self.net, L.lib()
+        dev = net.flat.device
+        rays_o, rays_d = rays
+        ro, rd = _f32c(rays_o.reshape(-1, 3)), _f32c(rays_d.reshape(-1, 3))
+        N, K, S, Ni = rd.shape[0], net.K_samples, int(N_samples), int(N_importance)
+        self._buffers(N, K)
+        st = L.stream()
+        L.check(lib.cfnerf_rays_setup(H, W, float(focal), None, L.ptr(ro), L.ptr(rd), N, 0, int(bool(ndc)), float(near), float(far),
+                                      L.ptr(self.packed), st), "cfnerf_rays_setup")
+        tv = torch.linspace(0., 1., steps=S).to(dev)
+        if perturb > 0.:
+            t_rand = _f32c(torch.rand(N, S, device=dev) if t_rand is None else t_rand)
+            u = _f32c(torch.rand(N, Ni, device=dev) if u_fine is None else u_fine)
+        else:
+            t_rand = None
+            u = _f32c(torch.linspace(0., 1., steps=Ni).expand(N, Ni).to(dev) if u_fine is None else u_fine)
+        eps = _f32c(net.draw_eps() if eps is None else eps)
+        net._sync()
+        net.ensure_workspace(N, S + Ni, K)
+        base = (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0) | L.F_TRAIN
+        target = _f32c(target)
+        beta_w, n_tot = C.c_float(self.beta1 / self.world), N * self.world
+        d_ent = L.ptr(self.d_ent) if self.beta1 else None
+        # 1. coarse pass (weights only) + resampling
+        w0 = torch.empty(N, S, K, device=dev)
+        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), None, L.ptr(eps), N, S, K, base,
+                                      L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth), None, L.ptr(w0), None, None,
+                                      L.ptr(self.entropy), st), "cfnerf_render_fwd")
+        z_all = torch.empty(N, S + Ni, device=dev)
+        L.check(lib.cfnerf_sample_pdf(L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), base, L.ptr(w0), L.ptr(u), N, S, K, Ni, L.ptr(z_all), st),
+                "cfnerf_sample_pdf")
+        grad_c = None
+        if coarse_loss:     # 2. coarse loss term: the same pass again, stashed, and its backward
+            L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), None, L.ptr(eps), N, S, K, base | L.F_STASH,
+                                          L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth), None, None, None, None,
+                                          L.ptr(self.entropy), st), "cfnerf_render_fwd")
+            L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(target), L.ptr(self.entropy), N, K, beta_w, n_tot, L.ptr(self.d_rgb),
+                                            L.ptr(self.scalars), st), "cfnerf_loss_fwd_bwd")
+            grad_c = torch.empty_like(self.grad)
+            L.check(lib.cfnerf_render_bwd(net.handle, lib.cfnerf_model_stash_generation(net.handle), L.ptr(self.d_rgb), None, d_ent,
+                                          L.ptr(grad_c), st), "cfnerf_render_bwd")
+            self.scalars_coarse = self.scalars.clone()
+        # 3. fine pass on the merged depths, loss, backward
+        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), None, L.ptr(z_all), L.ptr(eps), N, S + Ni, K, base | L.F_STASH,
+                                      L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth), None, None, None, None,
+                                      L.ptr(self.entropy), st), "cfnerf_render_fwd")
+        L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(target), L.ptr(self.entropy), N, K, beta_w, n_tot, L.ptr(self.d_rgb),
+                                        L.ptr(self.scalars), st), "cfnerf_loss_fwd_bwd")
+        L.check(lib.cfnerf_render_bwd(net.handle, lib.cfnerf_model_stash_generation(net.handle), L.ptr(self.d_rgb), None, d_ent,
+                                      L.ptr(self.grad), st), "cfnerf_render_bwd")
+        if grad_c is not None:
+            self.grad.add_(grad_c)
+        self.z_vals = z_all
+        return self.grad
+
+    def step_hierarchical(self, H, W, focal, rays, target, **kw):
+        """One full train step of the coarse + fine EXTENSION (see forward_backward_hierarchical)."""
+        dist_on = self.world > 1 or self.force_allreduce
+        if kw.get("eps") is None and dist_on:
+            kw["eps"] = self._step_eps()
+        self.forward_backward_hierarchical(H, W, focal, rays, target, **kw)
+        if dist_on:
+            self._queue_next_eps()
+            allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
+            self._take_next_eps()
+        lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
+        self.t += 1
+        net = self.net
+        L.check(L.lib().cfnerf_adam_step(net.handle, L.ptr(net.flat.data), L.ptr(self.grad), L.ptr(self.exp_avg),
+                                         L.ptr(self.exp_avg_sq), self.t, C.c_float(lr), C.c_float(1.0), L.stream()),
+                "cfnerf_adam_step")
+        net.mark_packed()
+        return self.scalars
+
     @property
     def global_step(self):
         return self.start + self.t

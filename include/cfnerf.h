@@ -151,7 +151,8 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
  * replaces: the loss lines RUN:1026-1050 (K-mean MSE/PSNR, KDE negative log-likelihood with the
  * detached n/(n-1)-scaled bandwidth, + beta1 * entropy).  Writes d(loss)/d(rgb_map) [N,3,K] and
  * scalars_out[4] = {loss, loss_nll, mse, psnr}.  `n_total` is the GLOBAL ray count the means are
- * taken over (N for one GPU, N * world_size when rays are sharded).                              */
+ * taken over (N for one GPU, N * world_size when rays are sharded).  scalars_out must be 8-byte aligned (its
+ * 16 bytes double as the two 64-bit fixed-point accumulators of the multi-workgroup reduction).     */
 int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K,
                         float beta1, int64_t n_total, float* d_rgb_map, float* scalars_out, cfnerf_stream s);
 

@@ -381,14 +381,16 @@ def sample_z(near: Tensor, far: Tensor, t_vals: Tensor, lindisp: bool, t_rand: O
 
 def render_rays(p, ray_batch: Tensor, cfg: OracleCfg, eps_alpha, eps_rgb, is_train: bool,
                 t_rand: Optional[Tensor] = None, lindisp: bool = False, white_bkgd: bool = False,
-                t_vals: Optional[Tensor] = None):
-    """ray_batch [N,11] = o3,d3,near,far,viewdir3 (RUN:504-507)."""
+                t_vals: Optional[Tensor] = None, z_vals: Optional[Tensor] = None):
+    """ray_batch [N,11] = o3,d3,near,far,viewdir3 (RUN:504-507).  ``z_vals`` [N,S] (EXTENSION only: explicit depths of
+    the fine pass) replaces the sampling lines RUN:510-532."""
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     viewdirs = ray_batch[:, -3:]
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
     if t_vals is None:
         t_vals = t_vals_table(ray_batch.dtype)
-    z_vals = sample_z(near, far, t_vals, lindisp, t_rand)
+    if z_vals is None:
+        z_vals = sample_z(near, far, t_vals, lindisp, t_rand)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]      # RUN:534
     raw, ent = run_network(p, pts, viewdirs, eps_alpha, eps_rgb, cfg, is_test=not is_train)   # RUN:537-538
     rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, white_bkgd)     # RUN:540
@@ -551,9 +553,7 @@ def render_rays_hierarchical(p, ray_batch: Tensor, cfg: OracleCfg, eps_alpha, ep
     w = coarse["weights"].mean(-1)                                   # [N,S]
     z_samples = sample_pdf(z_mid, w[..., 1:-1], u).detach()
     z_all, _ = torch.sort(torch.cat([z, z_samples], -1), -1)
-    rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]
-    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
-    raw, ent = run_network(p, pts, viewdirs, eps_alpha, eps_rgb, cfg, is_test=not is_train)
-    rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_all, rays_d, white_bkgd)
+    fine = render_rays(p, ray_batch, cfg, eps_alpha, eps_rgb, is_train, None, lindisp, white_bkgd, z_vals=z_all)
+    rgb_map, disp_map, weights, depth_map, ent = fine["rgb_map"], fine["disp_map"], fine["weights"], fine["depth_map"], fine.get("loss_entropy")
     return dict(rgb_map=rgb_map, disp_map=disp_map, depth_map=depth_map, weights=weights, z_vals=z_all, z_samples=z_samples,
                 rgb0=coarse["rgb_map"], disp0=coarse["disp_map"], depth0=coarse["depth_map"], loss_entropy=ent)
