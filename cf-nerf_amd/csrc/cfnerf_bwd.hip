@@ -95,9 +95,16 @@ __global__ __launch_bounds__(kThreads)
 void tail_bwd_kernel(const TailArgs A) {
     __shared__ float carry[kWaves][kMaxK];
     const int lane = lane_id_opaque(), wave = wave_id();
-    const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+    // one wave per (ray, k-part): a ray's K latent samples are independent up to the sums over k, which are left to the
+    // consumers (bwd_data adds the partial g_theta's while loading them, reduce_gms adds the rows), so small batches and
+    // large K still fill the chip (this kernel runs one wave per SIMD: ~360 registers)
+    const int64_t unit = (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t ray = unit / A.ksplit;
+    const int part = (int)(unit - ray * A.ksplit);
     if (ray >= A.N) return;
     const int S = A.S, K = A.K;
+    const int Kp = (K + A.ksplit - 1) / A.ksplit, k_lo = part * Kp, k_hi = min(K, k_lo + Kp);
+    float* __restrict__ g_theta_out = A.g_theta + (size_t)part * A.P * kThetaAll;
     const float* rr = A.rays + ray * 11;
     const float dnorm = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);
     const float cE = -((A.d_ent != nullptr) ? A.d_ent[0] : 0.f) / (float)((double)A.P * (double)K);
@@ -129,7 +136,7 @@ void tail_bwd_kernel(const TailArgs A) {
         const float dz = (s >= S - 1) ? 1e1f : A.z[p + 1] - zv;
         const float dist = dz * dnorm;
 
-        for (int k = 0; k < K; ++k) {
+        for (int k = k_lo; k < k_hi; ++k) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(A.raw + (p * K + k) * 4);
             const f32x2 at = *reinterpret_cast<const f32x2*>(A.at + (p * K + k) * 2);
             const float alpha = at[0], Tt = at[1];
@@ -242,7 +249,7 @@ void tail_bwd_kernel(const TailArgs A) {
 #pragma unroll
         for (int i = 72; i < 80; ++i) gth[i] *= (1.f - th[i] * th[i]);
         if (valid) {
-            f32x4* gp = reinterpret_cast<f32x4*>(A.g_theta + p * kThetaAll);
+            f32x4* gp = reinterpret_cast<f32x4*>(g_theta_out + p * kThetaAll);
 #pragma unroll
             for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = gth[q * 4]; v[1] = gth[q * 4 + 1]; v[2] = gth[q * 4 + 2]; v[3] = gth[q * 4 + 3]; gp[q] = v; }
             f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
@@ -258,7 +265,7 @@ void tail_bwd_kernel(const TailArgs A) {
     for (int i = 0; i < 8; ++i) gms[i] = wave_sum(gms[i]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) A.gms_partials[ray * 8 + i] = gms[i];
+        for (int i = 0; i < 8; ++i) A.gms_partials[unit * 8 + i] = gms[i];
     }
 }
 
@@ -363,7 +370,14 @@ void bwd_data_kernel(const BwdArgs A) {
         for (int idx = tid; idx < kTileM * (kThetaAll / 4); idx += kThreads) {
             const int row = idx >> 5, q = idx & 31;
             f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;
-            if (row < rows_valid) v = *reinterpret_cast<const f32x4*>(A.g_theta + (p0 + row) * kThetaAll + q * 4);
+            if (row < rows_valid) {
+                v = *reinterpret_cast<const f32x4*>(A.g_theta + (p0 + row) * kThetaAll + q * 4);
+                if (A.g_parts > 1) {                               // partial sums of the tail kernel's k-parts, fixed order;
+                    for (int part = 1; part < A.g_parts; ++part)   // the total goes back to part 0: the theta-head dW jobs read it
+                        v += *reinterpret_cast<const f32x4*>(A.g_theta + ((size_t)part * P + p0 + row) * kThetaAll + q * 4);
+                    *reinterpret_cast<f32x4*>(const_cast<float*>(A.g_theta) + (p0 + row) * kThetaAll + q * 4) = v;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD + q * 4 + c, v[c]);
         }
@@ -897,9 +911,8 @@ static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, 
 }
 
 constexpr size_t kDwBigLds = 4 * kDwRows * 256 * sizeof(float);
-// The 1 x 8 launch asks for more LDS than it uses (96 of 160 KB), so that two of its workgroups (122 VGPRs each) can
-// never be paired on one CU while another CU idles.
-constexpr size_t kDwNarrowLds = 96 * 1024;
+// (Asking for MORE dynamic LDS than the kernel uses - 96 KB, to keep two 1 x 8 workgroups off one CU - made that launch
+// produce wrong sums on this stack; the XCD-granular budgets of balance_big_splits make it unnecessary anyway.)
 constexpr size_t kDwSmallLds = 2 * kDwRows * kDsMaxCols * sizeof(float);
 
 // Per-DEVICE set-up of the backward kernels of one width (called from cfnerf_model_create with that device current)
@@ -912,8 +925,8 @@ hipError_t bwd_set_attributes(int W, int ha) {
     const void* bigs[4] = {reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 1>),
                            reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 1>)};
     hipError_t e = hipSuccess;
-    for (int q = 0; q < 4; ++q) {
-        e = hipFuncSetAttribute(bigs[q], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((q & 1) ? kDwNarrowLds : kDwBigLds));
+    for (const void* fn : bigs) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
         if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(dw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwSmallLds);
@@ -1106,6 +1119,44 @@ static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, 
     }
 }
 
+// The whole host-side plan of the weight-gradient launches for one workspace binding: tiles, per-tile splits, blocks
+// (2 x 4 tiles first, then the 1 x 8 tiles), small-job blocks and the per-tensor slot counts of the reduction.
+// Returns nullptr or the reason it cannot be built.
+static const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, const Stash& q, int64_t P, int n_cu, DwHost& Hs,
+                                 int* n_blocks_wide, int* ns_max_out) {
+    Hs.tiles.clear(); Hs.tiles_small.clear(); Hs.blocks.clear(); Hs.blocks_small.clear(); Hs.segs.clear();
+    build_dw_jobs(c, L, q, P, Hs.tiles, Hs.tiles_small);
+    // split counts: big tiles ~1 block per CU in total, balanced by per-tile cost; small jobs a finer split (their
+    // blocks are short and run several per CU)
+    const int kMaxSplit = 64;
+    balance_big_splits(Hs.tiles, n_cu, P, kMaxSplit);
+    int ns_small = kDwSlots;
+    while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
+    for (DwTile& t : Hs.tiles_small) t.nsplit = ns_small;
+    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
+    *n_blocks_wide = (int)Hs.blocks.size();
+    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
+    make_blocks(Hs.blocks_small, Hs.tiles_small, P, kDwRows);
+    if ((int)Hs.tiles.size() > kMaxDwTiles || (int)Hs.tiles_small.size() > kMaxDwTiles || (int)Hs.blocks.size() > kMaxDwBlocks ||
+        (int)Hs.blocks_small.size() > kMaxDwBlocks)
+        return "weight-gradient plan exceeds the descriptor capacity";
+    // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  The tiles of one tensor may use
+    // different counts (a big and a small tile of the skip / views layer; tiles that got a spare CU): the tensor is
+    // reduced over the largest, so the slots some tile never writes must read as zero - the caller clears them when
+    // the plan is (re)built, never on the steady path, where every launch rewrites exactly the slots it wrote before.
+    int ns_max = 1;
+    for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; Hs.segs.push_back(r); }
+    auto mark = [&](const std::vector<DwTile>& tv) {
+        for (const DwTile& t : tv)
+            for (int g = 0; g < t.nseg; ++g)
+                for (RedSeg& r : Hs.segs)
+                    if (r.begin == t.seg_dst[g]) { r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit); }
+    };
+    mark(Hs.tiles); mark(Hs.tiles_small);
+    *ns_max_out = ns_max;
+    return nullptr;
+}
+
 extern "C" {
 
 int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K, float beta1,
@@ -1150,36 +1201,8 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         DwHost& Hs = B.host[B.cur];
         if (Hs.uploaded) BHIP(hipEventSynchronize(Hs.uploaded));     // the upload made from THIS set two rebuilds ago is long done
         else BHIP(hipEventCreateWithFlags(&Hs.uploaded, hipEventDisableTiming));
-        Hs.tiles.clear(); Hs.tiles_small.clear(); Hs.blocks.clear(); Hs.blocks_small.clear(); Hs.segs.clear();
-        build_dw_jobs(c, L, q, P, Hs.tiles, Hs.tiles_small);
-        // split counts: big tiles ~1 block per CU in total, balanced by per-tile cost; small jobs a finer split (their
-        // blocks are short and run several per CU)
-        const int kMaxSplit = 64;
-        balance_big_splits(Hs.tiles, m->n_cu, P, kMaxSplit);
-        int ns_small = kDwSlots;
-        while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
-        for (DwTile& t : Hs.tiles_small) t.nsplit = ns_small;
-        make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
-        B.n_blocks_wide = (int)Hs.blocks.size();
-        make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
-        make_blocks(Hs.blocks_small, Hs.tiles_small, P, kDwRows);
-        if ((int)Hs.tiles.size() > kMaxDwTiles || (int)Hs.tiles_small.size() > kMaxDwTiles || (int)Hs.blocks.size() > kMaxDwBlocks ||
-            (int)Hs.blocks_small.size() > kMaxDwBlocks)
-            return bfail(CFNERF_E_UNSUPPORTED, "weight-gradient plan exceeds the descriptor capacity (%zu/%zu tiles, %zu/%zu blocks)",
-                         Hs.tiles.size(), Hs.tiles_small.size(), Hs.blocks.size(), Hs.blocks_small.size());
-        // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  The tiles of one tensor may use
-        // different counts (a big and a small tile of the skip / views layer; tiles that got a spare CU): the tensor is
-        // reduced over the largest, so the slots some tile never writes must read as zero - they are cleared HERE, when
-        // the plan is (re)built, never on the steady path, where every launch rewrites exactly the slots it wrote before.
         int ns_max = 1;
-        for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; Hs.segs.push_back(r); }
-        auto mark = [&](const std::vector<DwTile>& tv) {
-            for (const DwTile& t : tv)
-                for (int g = 0; g < t.nseg; ++g)
-                    for (RedSeg& r : Hs.segs)
-                        if (r.begin == t.seg_dst[g]) { r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit); }
-        };
-        mark(Hs.tiles); mark(Hs.tiles_small);
+        if (const char* why = build_dw_plan(c, L, q, P, m->n_cu, Hs, &B.n_blocks_wide, &ns_max)) return bfail(CFNERF_E_UNSUPPORTED, "%s", why);
         if (Hs.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
         BHIP(hipMemsetAsync(q.partials, 0, (size_t)ns_max * n_params * sizeof(float), st));
         auto up = [&](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
@@ -1200,8 +1223,13 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
     ta.d_rgb = d_rgb_map; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
     ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
+    // k-parts: the kernel runs ONE wave per SIMD, so split only while the waves still fit in one round (measured: a
+    // second round costs more than the shorter k-loops save); at most kTailParts and never more than K / 2
+    int ksplit = 1;
+    while (ksplit < kTailParts && ksplit * 2 <= q.K && N * ksplit * 2 <= (int64_t)m->n_cu * 4) ksplit *= 2;
+    ta.ksplit = ksplit;
     if (m->timing) BHIP(hipEventRecord(m->ev0[1], st));
-    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
+    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
     BHIP(hipGetLastError());
     if (m->timing) BHIP(hipEventRecord(m->ev1[1], st));
 
@@ -1209,7 +1237,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
     BwdArgs ba{};
     ba.tab = m->d_tab; ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
-    ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
+    ba.g_theta = q.g_theta; ba.g_parts = ksplit; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
@@ -1226,10 +1254,10 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         BHIP(hipEventRecord(m->ev_fork, st));
         BHIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
         if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwNarrowLds, m->side,
+            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
                                q.tiles, q.blocks + n_wide, q.partials, n_params);
         else
-            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwNarrowLds, m->side,
+            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
                                q.tiles, q.blocks + n_wide, q.partials, n_params);
         BHIP(hipGetLastError());
         BHIP(hipEventRecord(m->ev_join, m->side));
@@ -1255,7 +1283,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
                        q.bias_maps, (int)B.bias_maps.size(), grad_flat);
     BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N, m->flat, d_entropy, grad_flat);
+    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N * ksplit, m->flat, d_entropy, grad_flat);
     BHIP(hipGetLastError());
     if (m->timing) BHIP(hipEventRecord(m->ev1[3], st));
     return CFNERF_OK;
@@ -1306,3 +1334,38 @@ extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
     return n;
 }
 
+// the blocks of that plan for a given point count and CU count: 5 int64 per block {launch (0: 2 x 4, 1: 1 x 8, 2: small), tile, split,
+// pb, pe}; tile indices refer to the order cfnerf_debug_dw_plan reports (big tiles, then small tiles); plus per tile its nsplit and, per
+// parameter tensor, the slot count of the reduction.
+extern "C" int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
+                                      int32_t* seg_nsplit, int max_segs) {
+    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
+    ParamLayout L = build_layout(*cfg);
+    Stash q;
+    float* base = reinterpret_cast<float*>(uintptr_t(1) << 40);
+    const size_t step = size_t(1) << 36;
+    float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
+    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
+    DwHost H;
+    int n_wide = 0, ns_max = 0;
+    const char* why = build_dw_plan(*cfg, L, q, P, n_cu, H, &n_wide, &ns_max);
+    for (float** pp : ptrs) *pp = nullptr;
+    if (why) return CFNERF_E_UNSUPPORTED;
+    const int nb = (int)(H.blocks.size() + H.blocks_small.size());
+    if (nb > max_blocks || (int)L.e.size() > max_segs) return -nb;
+    int n = 0;
+    for (size_t i = 0; i < H.blocks.size(); ++i, ++n) {
+        const DwBlock& b = H.blocks[i];
+        int64_t* o = blocks_out + 5 * n;
+        o[0] = (int)i < n_wide ? 0 : 1; o[1] = b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
+    }
+    for (const DwBlock& b : H.blocks_small) {
+        int64_t* o = blocks_out + 5 * n++;
+        o[0] = 2; o[1] = (int64_t)H.tiles.size() + b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
+    }
+    int t = 0;
+    for (const DwTile& x : H.tiles) tile_nsplit[t++] = x.nsplit * (x.gk == 1 ? -1 : 1);     // sign: wave arrangement
+    for (const DwTile& x : H.tiles_small) tile_nsplit[t++] = x.nsplit;
+    for (size_t i = 0; i < H.segs.size(); ++i) seg_nsplit[i] = H.segs[i].nsplit;
+    return n;
+}

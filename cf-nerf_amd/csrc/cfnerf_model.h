@@ -13,6 +13,7 @@ namespace cfnerf {
 constexpr int kNumTimers = 5;   // 0 fwd, 1 bwd_tail, 2 bwd_data, 3 bwd_dw, 4 adam
 constexpr int kDwSlots = 128;   // split-K slots of the weight-gradient partials (upper bound of any split count)
 constexpr int kMaxDwTiles = 256, kMaxDwBlocks = 16384;     // descriptor capacities carved out of the workspace
+constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over up to this many waves (partial g_theta buffers)
 
 // Everything a CFNERF_F_STASH forward keeps for cfnerf_render_bwd plus every buffer the backward writes, carved out of
 // ONE block of device memory: either handed in by the caller (cfnerf_model_set_workspace, sized with
@@ -35,8 +36,8 @@ struct Stash {
     float *at = nullptr;     // [P,K,2]  alpha, T
     float *mbits = nullptr;  // [D+1][tiles][W/32][64] u32 ReLU mask words (fragment order)
     // ---- written by the backward (same row-major-per-point convention)
-    float *gms = nullptr;       // [N,8]    base-Gaussian gradient partials
-    float *g_theta = nullptr;   // [P,128]  d loss / d theta (pre-tanh for the diagonal columns)
+    float *gms = nullptr;       // [N*parts,8]    base-Gaussian gradient partials
+    float *g_theta = nullptr;   // [parts][P,128]  d loss / d theta (pre-tanh for the diagonal columns), one partial per k-part
     float *g_hr = nullptr;      // [P,HR]
     float *g_ha = nullptr;      // [P,HA]
     float *g_v = nullptr;       // [P,W/2]  pre-activation gradient of the views layer
@@ -81,8 +82,8 @@ struct Stash {
         take(&t->theta, (size_t)P * kThetaAll, 4); take(&t->z, (size_t)P + 1, 4); take(&t->raw, (size_t)P * k * 4, 4);
         take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
         take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
-        take(&t->gms, (size_t)(n + 8) * 8, 4);
-        take(&t->g_theta, (size_t)P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);
+        take(&t->gms, (size_t)(n * kTailParts + 8) * 8, 4);
+        take(&t->g_theta, (size_t)kTailParts * P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);
         take(&t->g_ha, (size_t)P * c.h_alpha_size, 4); take(&t->g_v, (size_t)P * (W / 2), 4);
         take(&t->g_feat, (size_t)P * W, 4); take(&t->g_h, (size_t)D * P * W, 4);
         take(&t->dbp, (size_t)n_wg * nb, 4);

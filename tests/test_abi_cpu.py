@@ -204,3 +204,49 @@ def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
             assert (c == 1).all(), (key, int(c.min()), int(c.max()))
         else:
             assert (c == 0).all(), (key, int(c.max()))
+
+
+@pytest.mark.parametrize("W,D,P,n_cu", [(256, 8, 131072, 256), (128, 8, 5120, 256), (256, 8, 1024, 256), (512, 8, 65536, 256), (64, 4, 640, 256),
+                                        (256, 8, 524288, 256), (128, 6, 33 * 130, 256), (256, 8, 131072, 64)])
+def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
+    """Host logic of the backward: for every tile the blocks' point ranges tile [0, P) exactly once, their split slots
+    are 0 .. nsplit-1, every tensor is reduced over at least the slots its tiles write, and the two big launches
+    together never exceed one workgroup per CU (in whole workgroups per XCD: see balance_big_splits)."""
+    lib = L.lib()
+    fn = lib.cfnerf_debug_dw_blocks
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
+    lib.cfnerf_debug_dw_plan.restype = C.c_int
+    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
+    cfg = L.Cfg(D, W, 10, 4, 32, 64, 4)
+    cap = 20000
+    blocks = (C.c_int64 * (5 * cap))()
+    tile_ns = (C.c_int32 * 1024)()
+    seg_ns = (C.c_int32 * 256)()
+    n = fn(C.byref(cfg), P, n_cu, blocks, cap, tile_ns, seg_ns, 256)
+    assert n > 0
+    b = np.ctypeslib.as_array(blocks).reshape(cap, 5)[:n]
+    tiles = (C.c_int32 * (16 * 1024))()
+    segdst = (C.c_uint32 * (4 * 1024))()
+    nt = lib.cfnerf_debug_dw_plan(C.byref(cfg), P, tiles, segdst, 1024)
+    t = np.ctypeslib.as_array(tiles).reshape(1024, 16)[:nt]
+    sd = np.ctypeslib.as_array(segdst).reshape(1024, 4)[:nt]
+    ns = np.ctypeslib.as_array(tile_ns)[:nt]
+    layout, _ = cfnerf_amd.param_layout(cfg)
+    seg_of = {off: i for i, (k, (off, cnt)) in enumerate(layout.items())}
+    seg_n = np.ctypeslib.as_array(seg_ns)
+    for ti in range(nt):
+        mine = b[b[:, 1] == ti]
+        want_launch = 2 if not t[ti, 0] else (1 if ns[ti] < 0 else 0)
+        assert (mine[:, 0] == want_launch).all(), (ti, mine[:, 0])
+        nsplit = abs(int(ns[ti]))
+        assert sorted(mine[:, 2].tolist()) == list(range(nsplit)), (ti, nsplit, sorted(mine[:, 2].tolist()))
+        order = np.argsort(mine[:, 3])
+        assert mine[order[0], 3] == 0 and mine[order[-1], 4] == P
+        assert (mine[order[1:], 3] == mine[order[:-1], 4]).all(), "gaps or overlaps in the point ranges"
+        assert ((mine[:, 4] - mine[:, 3]) > 0).all()
+        for g in range(int(t[ti, 7])):
+            assert seg_n[seg_of[int(sd[ti, g])]] >= nsplit
+    n_wide, n_narrow = int((b[:, 0] == 0).sum()), int((b[:, 0] == 1).sum())
+    per_xcd = n_cu // 8
+    assert -(-n_wide // 8) + -(-n_narrow // 8) <= per_xcd, (n_wide, n_narrow)
