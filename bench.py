@@ -178,7 +178,8 @@ class Workload:
             self.target = torch.tensor(rng.uniform(0, 1, (self.n, 3)), dtype=torch.float32).to(dev)
         if self.mode == "train":
             from cfnerf_amd import train as T
-            self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist)
+            self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist,
+                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "1") != "0")
         self.hier = hierarchical
 
     def step(self):

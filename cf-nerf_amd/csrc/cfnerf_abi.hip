@@ -56,9 +56,6 @@ static int model_init_device(cfnerf_model* m) {
         HIPCHK(hipEventCreate(&m->ev0[i]));
         HIPCHK(hipEventCreate(&m->ev1[i]));
     }
-    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     m->ws_bytes = pbytes + sizeof(NetTab);
     // launch attributes and occupancy belong to (kernel, device): set here, with the model's device current
     HIPCHK(fused_fwd_set_attributes(cfg->netwidth, cfg->h_alpha_size, &m->fwd_blocks_per_cu));
@@ -168,9 +165,6 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     m->stash.release();
     m->bwd.release();
     for (int i = 0; i < kNumTimers; ++i) { if (m->ev0[i]) hipEventDestroy(m->ev0[i]); if (m->ev1[i]) hipEventDestroy(m->ev1[i]); }
-    if (m->ev_fork) hipEventDestroy(m->ev_fork);
-    if (m->ev_join) hipEventDestroy(m->ev_join);
-    if (m->side) hipStreamDestroy(m->side);
     delete m;
     return CFNERF_OK;
 }

@@ -49,7 +49,9 @@ struct DwTile {
 struct BiasMap { int32_t col0, count; uint32_t dst; };
 
 // a parameter tensor's start offset and the number of split slots its gradient partials occupy
-struct RedSeg { uint32_t begin; int32_t nsplit; };
+// nsplit: slots to sum; -1 = not written by the weight reduction (biases: reduce_bias, base Gaussians: reduce_gms).
+// early: 1 = every tile of the tensor belongs to the big launches, so its sum is final BEFORE the small-job launch.
+struct RedSeg { uint32_t begin; int32_t nsplit; int32_t early; int32_t pad_; };
 
 // one workgroup of a weight-gradient launch: tile index, split slot and its point range
 struct DwBlock { int32_t tile, split, kslice, pad_; int64_t pb, pe; };
@@ -70,8 +72,12 @@ struct BwdPlan {
     int cur = 0;                                          // the set the device copies were made from
     uint64_t bind_serial = ~0ull;                         // Stash::bind_serial the descriptors were built for
     int n_blocks_wide = 0;                                // blocks[0, n_blocks_wide): 2 x 4 tiles; the rest: 1 x 8 tiles
+    hipEvent_t ev_early = nullptr;                        // recorded once the "early" tensors' gradients are final
+    std::vector<int64_t> early_off, early_cnt;            // flat ranges of grad_flat that are final at ev_early (merged, sorted)
     void release() {
         for (DwHost& h : host) { if (h.uploaded) (void)hipEventDestroy(h.uploaded); h.uploaded = nullptr; }
+        if (ev_early) (void)hipEventDestroy(ev_early);
+        ev_early = nullptr;
         bind_serial = ~0ull;
     }
 };

@@ -492,31 +492,48 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 constexpr int kDwRows = 32;                   // points per LDS stage
 constexpr int kDwThreads = 512;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// a function's arguments arrive in VECTOR registers: tell the compiler they are wave-uniform, or every buffer load built
+// from them is wrapped in a waterfall loop (cdna_hip_programming.md T20)
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 template <int PREC, int ARR>
-__global__ __launch_bounds__(kDwThreads, 2)
-void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
+__device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
+                                                      float* __restrict__ partials_, int64_t n_params_) {
+    const DwTile* __restrict__ tiles = uniform_ptr(tiles_);
+    const DwBlock* __restrict__ blocks = uniform_ptr(blocks_);
+    float* __restrict__ partials = uniform_ptr(partials_);
+    const int64_t n_params = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)n_params_ >> 32)) << 32) |
+                                       __builtin_amdgcn_readfirstlane((unsigned)n_params_));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                 // [2][32][256]
     float* Bs = smem + 2 * kDwRows * 256;             // [2][32][256]
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
     const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
-    constexpr bool arr1 = ARR == 1;                   // the wave arrangement is a property of the launch (two register
-                                                      // allocations: one kernel holding both loop nests spilt its accumulators)
+    constexpr bool arr1 = ARR == 1;                   // the wave arrangement picks one of two NON-INLINED bodies (two register
+                                                      // allocations: one function holding both loop nests spilt its accumulators)
     const int wn = arr1 ? 0 : wave >> 2, wk = arr1 ? wave : wave & 3;
     const int rows = (int)(blk.pe - blk.pb);          // a split's point range is far below 2^31 bytes / row
     // loader geometry: thread -> (row = tid / 64 + 8 * q, 16-B column c = tid % 64)
     const int lrow = tid >> 6, lc = tid & 63;
     const bool a_col_ok = t.n0 + 4 * lc + 4 <= t.Npad, b_col_ok = t.k0 + 4 * lc + 4 <= t.Kpad;
-    const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.dY + blk.pb * t.ldY), 0, rows * t.ldY * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.X + blk.pb * t.ldX), 0, rows * t.ldX * 4, 0x00020000);
+    // descriptor inputs through readfirstlane: they ARE wave-uniform, this makes it provable (no waterfall loops, T20)
+    const int ldY = __builtin_amdgcn_readfirstlane(t.ldY), ldX = __builtin_amdgcn_readfirstlane(t.ldX);
+    const int rows_u = __builtin_amdgcn_readfirstlane(rows);
+    const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float*>(t.dY + blk.pb * t.ldY)), 0, rows_u * ldY * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float*>(t.X + blk.pb * t.ldX)), 0, rows_u * ldX * 4, 0x00020000);
     int va[4], vb[4];                                 // byte offsets of this thread's four rows of a stage; out of range = zeros
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         va[q] = a_col_ok ? ((lrow + 8 * q) * t.ldY + t.n0 + 4 * lc) * 4 : 0x7ffffff0;
         vb[q] = b_col_ok ? ((lrow + 8 * q) * t.ldX + t.k0 + 4 * lc) * 4 : 0x7ffffff0;
     }
-    const int sa_step = kDwRows * t.ldY * 4, sb_step = kDwRows * t.ldX * 4;
+    const int sa_step = kDwRows * ldY * 4, sb_step = kDwRows * ldX * 4;
     int sa = 0, sb = 0;                               // scalar stage offsets
     f32x4 ra[4], rb[4];
     auto gload = [&]() {
@@ -561,8 +578,8 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
     sstore(0);
     __syncthreads();
     int buf = 0;
-    for (int p = 0; p < rows; p += kDwRows) {
-        const bool more = p + kDwRows < rows;
+    for (int p = 0; p < rows_u; p += kDwRows) {      // uniform trip count: keeps the stage offsets in scalar registers
+        const bool more = p + kDwRows < rows_u;
         if (more) gload();
         __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
         if (active) {
@@ -648,6 +665,15 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
         if (arr1) dw_store_tile<1>(t, out, acc, t.n0, t.k0 + 32 * wk, lane);
         else      dw_store_tile<2>(t, out, acc, t.n0 + 128 * wn, t.k0 + 64 * wk, lane);
     }
+}
+
+// ONE launch for both arrangements: every workgroup has the same resource footprint (one per CU), so any mix of 2 x 4
+// and 1 x 8 blocks fills the chip one block per CU with no second stream and no placement assumptions.
+template <int PREC>
+__global__ __launch_bounds__(kDwThreads, 2)
+void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
+    if (tiles[blocks[blockIdx.x].tile].gk == 1) dw_big_body<PREC, 1>(tiles, blocks, partials, n_params);
+    else                                        dw_big_body<PREC, 0>(tiles, blocks, partials, n_params);
 }
 
 // ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  Same scheme as 4a at a finer grain:
@@ -801,13 +827,15 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
 // ================================================================================================
 // 5. reductions into grad_flat
 // grad[i] = sum over the split slots that the tensor containing i actually uses (segments sorted by offset)
+// phase 1: only the tensors whose tiles all belong to the big launches (final before the small-job launch); phase 0: the rest
 __global__ void reduce_weights_kernel(const float* __restrict__ partials, const RedSeg* __restrict__ segs, int n_segs, int64_t n_params,
-                                      float* __restrict__ grad) {
+                                      float* __restrict__ grad, int phase) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_params) return;
     int lo = 0, hi = n_segs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)segs[mid].begin <= i) lo = mid; else hi = mid - 1; }
     const int ns = segs[lo].nsplit;
+    if (ns < 0 || segs[lo].early != phase) return;
     // 8 independent loads per trip (the slots of one element are n_params apart: latency-bound otherwise); fixed
     // summation order, so the result is deterministic
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -922,8 +950,7 @@ hipError_t bwd_set_attributes(int W, int ha) {
         hipError_t e = hipFuncSetAttribute(bwd_data_fn(W, b16 != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const void* bigs[4] = {reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_F32, 1>),
-                           reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 0>), reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3, 1>)};
+    const void* bigs[2] = {reinterpret_cast<const void*>(dw_big_kernel<PREC_F32>), reinterpret_cast<const void*>(dw_big_kernel<PREC_BF16X3>)};
     hipError_t e = hipSuccess;
     for (const void* fn : bigs) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwBigLds);
@@ -1084,38 +1111,25 @@ static void make_blocks(std::vector<DwBlock>& blocks, std::vector<DwTile>& tiles
     std::stable_sort(blocks.begin() + first, blocks.end(), [](const DwBlock& a, const DwBlock& b) { return (a.pe - a.pb) > (b.pe - b.pb); });
 }
 
-// Split counts of the big tiles.  The 2 x 4 launch and (if the network has N <= 128 tiles) the 1 x 8 launch run side by
-// side, one workgroup per CU in total (their register budgets do not allow two on a CU).  Workgroups are dealt to the 8
-// XCDs round-robin, and where a launch's deal starts is not ours to choose, so an XCD may receive ceil(n / 8)
-// workgroups of EACH launch: the budgets are whole numbers of workgroups per XCD, 8 r for the 1 x 8 launch and
-// 8 (cu_per_xcd - r) for the 2 x 4 launch.  (Measured with 18 + 238 blocks: one XCD got 33, a 1 x 8 block waited for a
-// whole 2 x 4 block and the pair of launches took 2.05 ms instead of 1.1.)  r balances the two launches' block times;
-// a 1 x 8 block issues about 0.59 of a 2 x 4 block's work per point.
+// Split counts of the big tiles: one block per CU in total (every block of the launch has the same footprint, so the
+// hardware places exactly one per CU whatever the mix), points shared out so that every block takes about the same time:
+// a 1 x 8 block (N <= 128) issues half the MFMAs per stage of a 2 x 4 block but pays the same fixed cost per stage, ~0.59
+// of its time per point (measured), so it gets proportionally more points.
 static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, int max_split) {
     if (tiles.empty()) return;
-    const int kXcd = 8, per_xcd = std::max(1, n_cu / kXcd);
+    auto cost = [](const DwTile& t) { return t.gk == 1 ? 0.59 : 1.0; };
+    double total = 0;
+    for (const DwTile& t : tiles) total += cost(t);
     int cap = max_split;
     while (cap > 1 && P / cap < 512) --cap;                  // at least 512 points per block
-    int n_wide_t = 0, n_narrow_t = 0;
-    for (const DwTile& t : tiles) (t.gk == 1 ? n_narrow_t : n_wide_t)++;
-    int budget[2] = {kXcd * per_xcd, 0};                     // blocks of the 2 x 4 / 1 x 8 launch
-    if (n_narrow_t > 0 && n_wide_t > 0) {
-        int best_r = 1; double best = 1e30;
-        for (int r = 1; r < per_xcd; ++r) {
-            const double tn = 0.59 * n_narrow_t / (kXcd * r), tw = 1.0 * n_wide_t / (kXcd * (per_xcd - r));
-            if (std::max(tn, tw) < best) { best = std::max(tn, tw); best_r = r; }
-        }
-        budget[1] = kXcd * best_r; budget[0] = kXcd * (per_xcd - best_r);
-    } else if (n_narrow_t > 0) {
-        budget[1] = budget[0]; budget[0] = 0;
-    }
-    for (int arr = 0; arr < 2; ++arr) {
-        const int nt = arr ? n_narrow_t : n_wide_t;
-        if (nt == 0) continue;
-        const int base = std::max(1, std::min(cap, budget[arr] / nt));
-        int extra = (base < cap) ? std::max(0, budget[arr] - base * nt) : 0;
+    int used = 0;
+    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(n_cu * cost(t) / total))); used += t.nsplit; }
+    while (used < n_cu) {                                    // hand the remaining CUs to the tiles whose blocks are longest
+        DwTile* best = nullptr;
         for (DwTile& t : tiles)
-            if (t.gk == arr) { t.nsplit = base + (extra > 0 ? 1 : 0); if (extra > 0) --extra; }
+            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
+        if (!best) break;
+        ++best->nsplit; ++used;
     }
 }
 
@@ -1133,9 +1147,9 @@ static const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, cons
     int ns_small = kDwSlots;
     while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
     for (DwTile& t : Hs.tiles_small) t.nsplit = ns_small;
-    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 0);           // 2 x 4 tiles first ...
-    *n_blocks_wide = (int)Hs.blocks.size();
-    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows, 1);           // ... then the 1 x 8 tiles (their own launch, side stream)
+    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows);              // one launch: longest blocks first, whatever their arrangement
+    *n_blocks_wide = 0;
+    for (const DwBlock& b : Hs.blocks) *n_blocks_wide += Hs.tiles[b.tile].gk == 0;
     make_blocks(Hs.blocks_small, Hs.tiles_small, P, kDwRows);
     if ((int)Hs.tiles.size() > kMaxDwTiles || (int)Hs.tiles_small.size() > kMaxDwTiles || (int)Hs.blocks.size() > kMaxDwBlocks ||
         (int)Hs.blocks_small.size() > kMaxDwBlocks)
@@ -1145,16 +1159,41 @@ static const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, cons
     // reduced over the largest, so the slots some tile never writes must read as zero - the caller clears them when
     // the plan is (re)built, never on the steady path, where every launch rewrites exactly the slots it wrote before.
     int ns_max = 1;
-    for (const ParamEntry& e : L.e) { RedSeg r; r.begin = (uint32_t)e.off; r.nsplit = 0; Hs.segs.push_back(r); }
-    auto mark = [&](const std::vector<DwTile>& tv) {
+    for (const ParamEntry& e : L.e) { RedSeg r{}; r.begin = (uint32_t)e.off; r.nsplit = 0; r.early = 0; Hs.segs.push_back(r); }
+    auto mark = [&](const std::vector<DwTile>& tv, bool big) {
         for (const DwTile& t : tv)
             for (int g = 0; g < t.nseg; ++g)
                 for (RedSeg& r : Hs.segs)
-                    if (r.begin == t.seg_dst[g]) { r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit); }
+                    if (r.begin == t.seg_dst[g]) {
+                        if (r.nsplit == 0) r.early = big ? 1 : 0; else if (!big) r.early = 0;
+                        r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit);
+                    }
     };
-    mark(Hs.tiles); mark(Hs.tiles_small);
+    mark(Hs.tiles, true); mark(Hs.tiles_small, false);
     *ns_max_out = ns_max;
     return nullptr;
+}
+
+// Which kernel writes a tensor's gradient, and when it is final:
+//   biases (reduce_bias, right after bwd_data) and the base Gaussians (reduce_gms, right after the tail): nsplit = -1, the
+//   weight reduction skips them; dead tensors: zeros, written with the early phase; a weight fed only by big tiles: early.
+// B.early_off / early_cnt: the merged flat ranges of grad_flat that are final when ev_early fires (before dw_small runs),
+// so that a multi-GPU caller can start exchanging them while the small jobs still compute.
+static void finish_segs(const ParamLayout& L, BwdPlan& B, DwHost& Hs) {
+    for (size_t i = 0; i < Hs.segs.size(); ++i) {
+        RedSeg& r = Hs.segs[i];
+        bool by_other = i < 4;                                   // alpha_mean, alpha_std, rgb_mean, rgb_std: reduce_gms
+        for (const BiasMap& bm : B.bias_maps) by_other = by_other || bm.dst == r.begin;
+        if (by_other) { r.nsplit = -1; r.early = 1; }
+        else if (r.nsplit == 0) r.early = 1;
+    }
+    B.early_off.clear(); B.early_cnt.clear();
+    for (size_t i = 0; i < Hs.segs.size(); ++i) {
+        if (!Hs.segs[i].early) continue;
+        const int64_t b = Hs.segs[i].begin, e = (i + 1 < Hs.segs.size()) ? (int64_t)Hs.segs[i + 1].begin : L.total;
+        if (!B.early_off.empty() && B.early_off.back() + B.early_cnt.back() == b) B.early_cnt.back() += e - b;
+        else { B.early_off.push_back(b); B.early_cnt.push_back(e - b); }
+    }
 }
 
 extern "C" {
@@ -1203,6 +1242,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         else BHIP(hipEventCreateWithFlags(&Hs.uploaded, hipEventDisableTiming));
         int ns_max = 1;
         if (const char* why = build_dw_plan(c, L, q, P, m->n_cu, Hs, &B.n_blocks_wide, &ns_max)) return bfail(CFNERF_E_UNSUPPORTED, "%s", why);
+        finish_segs(L, B, Hs);
         if (Hs.segs.size() > 256) return bfail(CFNERF_E_UNSUPPORTED, "too many parameter tensors");
         BHIP(hipMemsetAsync(q.partials, 0, (size_t)ns_max * n_params * sizeof(float), st));
         auto up = [&](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
@@ -1231,9 +1271,11 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     if (m->timing) BHIP(hipEventRecord(m->ev0[1], st));
     hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
     BHIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N * ksplit, m->flat, d_entropy, grad_flat);
+    BHIP(hipGetLastError());
     if (m->timing) BHIP(hipEventRecord(m->ev1[1], st));
 
-    // ---- 2. fused backward-data (+ bias partials)
+    // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
     BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
     BwdArgs ba{};
     ba.tab = m->d_tab; ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
@@ -1244,48 +1286,54 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));
     BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, st, &grid_bd));
     if (m->timing) BHIP(hipEventRecord(m->ev1[2], st));
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
+                       q.bias_maps, (int)B.bias_maps.size(), grad_flat);
+    BHIP(hipGetLastError());
 
     // ---- 3. weight gradients + reductions
     if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
-    // the 1 x 8 tiles (N <= 128: a handful of blocks) run on the model's side stream NEXT TO the 2 x 4 launch: the split
-    // balance hands them the CUs the 2 x 4 launch leaves free (fork / join with events: no host synchronisation)
-    const int n_wide = B.n_blocks_wide, n_narrow = (int)Hc.blocks.size() - n_wide;
-    if (n_narrow > 0) {
-        BHIP(hipEventRecord(m->ev_fork, st));
-        BHIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    if (!Hc.blocks.empty()) {
         if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
-                               q.tiles, q.blocks + n_wide, q.partials, n_params);
-        else
-            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 1>), dim3((unsigned)n_narrow), dim3(kDwThreads), kDwBigLds, m->side,
-                               q.tiles, q.blocks + n_wide, q.partials, n_params);
-        BHIP(hipGetLastError());
-        BHIP(hipEventRecord(m->ev_join, m->side));
-    }
-    if (n_wide > 0) {
-        if (m->precision == PREC_BF16X3)
-            hipLaunchKernelGGL((dw_big_kernel<PREC_BF16X3, 0>), dim3((unsigned)n_wide), dim3(kDwThreads), kDwBigLds, st,
+            hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)Hc.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
                                q.tiles, q.blocks, q.partials, n_params);
         else
-            hipLaunchKernelGGL((dw_big_kernel<PREC_F32, 0>), dim3((unsigned)n_wide), dim3(kDwThreads), kDwBigLds, st,
+            hipLaunchKernelGGL(dw_big_kernel<PREC_F32>, dim3((unsigned)Hc.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
                                q.tiles, q.blocks, q.partials, n_params);
         BHIP(hipGetLastError());
     }
-    if (n_narrow > 0) BHIP(hipStreamWaitEvent(st, m->ev_join, 0));
+    // tensors fed by big tiles only (+ the zeros of dead tensors): final now.  ev_early lets a multi-GPU caller start
+    // exchanging B.early_off / early_cnt while the small jobs below still compute.
+    const unsigned red_grid = (unsigned)((n_params + 255) / 256);
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 1);
+    BHIP(hipGetLastError());
+    if (!B.ev_early) BHIP(hipEventCreateWithFlags(&B.ev_early, hipEventDisableTiming));
+    BHIP(hipEventRecord(B.ev_early, st));
     if (!Hc.blocks_small.empty()) {
         hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)Hc.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
                            q.tiles_small, q.blocks_small, q.partials, n_params, q.zeros);
         BHIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_weights_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(),
-                       n_params, grad_flat);
-    BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
-                       q.bias_maps, (int)B.bias_maps.size(), grad_flat);
-    BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N * ksplit, m->flat, d_entropy, grad_flat);
+    hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 0);
     BHIP(hipGetLastError());
     if (m->timing) BHIP(hipEventRecord(m->ev1[3], st));
+    return CFNERF_OK;
+}
+
+// The flat ranges of grad_flat that are final when the early event of the LAST cfnerf_render_bwd fires (they do not
+// depend on the batch: only on which tensors are fed by big tiles).  Returns the number of ranges (<= max), < 0 on error.
+int cfnerf_grad_early_ranges(cfnerf_model* m, int64_t* offsets, int64_t* counts, int max_ranges) {
+    if (!m || !offsets || !counts) return bfail(CFNERF_E_INVALID, "NULL argument");
+    if (m->bwd.early_off.empty()) return bfail(CFNERF_E_INVALID, "no backward has run on this model yet");
+    const int n = (int)m->bwd.early_off.size();
+    if (n > max_ranges) return bfail(CFNERF_E_INVALID, "%d ranges, room for %d", n, max_ranges);
+    for (int i = 0; i < n; ++i) { offsets[i] = m->bwd.early_off[i]; counts[i] = m->bwd.early_cnt[i]; }
+    return n;
+}
+
+int cfnerf_stream_wait_grad_early(cfnerf_model* m, cfnerf_stream waiter) {
+    if (!m) return bfail(CFNERF_E_INVALID, "model is NULL");
+    if (!m->bwd.ev_early) return bfail(CFNERF_E_INVALID, "no backward has run on this model yet");
+    BHIP(hipStreamWaitEvent((hipStream_t)waiter, m->bwd.ev_early, 0));
     return CFNERF_OK;
 }
 
@@ -1334,7 +1382,7 @@ extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
     return n;
 }
 
-// the blocks of that plan for a given point count and CU count: 5 int64 per block {launch (0: 2 x 4, 1: 1 x 8, 2: small), tile, split,
+// the blocks of that plan for a given point count and CU count: 5 int64 per block {kind (0: 2 x 4, 1: 1 x 8, 2: small job), tile, split,
 // pb, pe}; tile indices refer to the order cfnerf_debug_dw_plan reports (big tiles, then small tiles); plus per tile its nsplit and, per
 // parameter tensor, the slot count of the reduction.
 extern "C" int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
@@ -1357,7 +1405,7 @@ extern "C" int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu
     for (size_t i = 0; i < H.blocks.size(); ++i, ++n) {
         const DwBlock& b = H.blocks[i];
         int64_t* o = blocks_out + 5 * n;
-        o[0] = (int)i < n_wide ? 0 : 1; o[1] = b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
+        o[0] = H.tiles[b.tile].gk == 1 ? 1 : 0; o[1] = b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
     }
     for (const DwBlock& b : H.blocks_small) {
         int64_t* o = blocks_out + 5 * n++;

@@ -123,8 +123,6 @@ struct cfnerf_model {
     int fwd_blocks_per_cu = 1;            // occupancy of the fused forward on THIS device (set at create)
     bool timing = false;
     hipEvent_t ev0[cfnerf::kNumTimers]{}, ev1[cfnerf::kNumTimers]{};
-    hipStream_t side = nullptr;           // second stream for launches that run NEXT TO one on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t ws_bytes = 0;
 };
 

@@ -67,8 +67,10 @@ class Trainer:
     the step-t gradient all-reduce (the other ranks contribute zeros there), so no extra collective and no reliance on
     identical seeding; step 0 uses one broadcast.  An explicit ``eps=`` argument overrides this (tests, benchmarks)."""
 
-    def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False):
+    def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False,
+                 overlap_comm=True):
         self.force_allreduce = bool(force_allreduce)
+        self.overlap_comm = bool(overlap_comm)
         self.net: NeRF_Flows = _unwrap(net)
         dev = self.net.flat.device
         self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
@@ -90,6 +92,48 @@ class Trainer:
         self.entropy = torch.zeros(1, device=dev)
         self.t = 0
         self._buf_n = None
+
+    # ---- gradient exchange ---------------------------------------------------------------------------------------
+    def _exchange_plan(self):
+        """Index tensors of the two buckets: `early` = flat ranges that are final before the backward's last launch
+        (cfnerf_grad_early_ranges), `late` = the rest + the latents tail.  Built once, after the first backward."""
+        if getattr(self, "_xplan", None) is None:
+            lib, n = L.lib(), self.net.n_params
+            offs, cnts = (C.c_int64 * 64)(), (C.c_int64 * 64)()
+            k = lib.cfnerf_grad_early_ranges(self.net.handle, offs, cnts, 64)
+            if k < 0:
+                raise RuntimeError("cfnerf_grad_early_ranges: " + lib.cfnerf_last_error().decode())
+            dev = self.gbuf.device
+            mask = torch.zeros(self.gbuf.numel(), dtype=torch.bool, device=dev)
+            for i in range(k):
+                mask[offs[i]:offs[i] + cnts[i]] = True
+            idx = torch.arange(self.gbuf.numel(), device=dev)
+            self._xplan = (idx[mask], idx[~mask])
+            self._comm = torch.cuda.Stream(device=dev)
+        return self._xplan
+
+    def _exchange(self):
+        """Sum the gradient (and the latents tail) over the ranks.  With an RCCL group: two buckets - the early one is
+        gathered and all-reduced on a side stream as soon as its tensors are final, i.e. UNDER the small-job launch that
+        ends the backward; the late one (the small jobs' tensors, ~1/4 of the bytes) follows on the main stream.  A gloo
+        group (tests) or `overlap_comm=False`: one all-reduce of the whole buffer."""
+        import torch.distributed as dist
+        if not self.overlap_comm or not self.gbuf.is_cuda or dist.get_backend(self.group) != "nccl":
+            allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
+            return
+        early, late = self._exchange_plan()
+        main = torch.cuda.current_stream(self.gbuf.device)
+        L.check(L.lib().cfnerf_stream_wait_grad_early(self.net.handle, C.c_void_p(self._comm.cuda_stream)), "cfnerf_stream_wait_grad_early")
+        with torch.cuda.stream(self._comm):
+            e_buf = self.gbuf.index_select(0, early)
+            w_early = dist.all_reduce(e_buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        l_buf = self.gbuf.index_select(0, late)
+        dist.all_reduce(l_buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.gbuf.index_copy_(0, late, l_buf)
+        w_early.wait()                              # the main stream waits for the side stream's all-reduce
+        main.wait_stream(self._comm)
+        self.gbuf.index_copy_(0, early, e_buf)
+        e_buf.record_stream(main)
 
     def _step_eps(self):
         """Latents of the coming step, identical on every rank."""
@@ -179,7 +223,7 @@ class Trainer:
         self.forward_backward(H, W, focal, rays, target, **kw)
         if dist_on:
             self._queue_next_eps()
-            allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
+            self._exchange()
             self._take_next_eps()
         lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
         self.t += 1

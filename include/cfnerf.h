@@ -178,6 +178,16 @@ uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
 int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
                       const float* d_entropy, float* grad_flat, cfnerf_stream s);
 
+/* ---- overlap of the multi-GPU gradient exchange with the end of the backward --------------------------------
+ * replaces: nothing in the reference (its nn.DataParallel, RUN:330, gathers gradients inside autograd).  Most of
+ * grad_flat - every bias, the base Gaussians, and each weight whose gradient comes from the big weight-gradient
+ * launches alone - is final BEFORE the small-job launch that ends cfnerf_render_bwd.  cfnerf_grad_early_ranges
+ * reports those flat ranges (they depend on the configuration only; available after the first cfnerf_render_bwd);
+ * cfnerf_stream_wait_grad_early makes `waiter` (e.g. the communication stream) wait for the event recorded at
+ * that point of the LAST cfnerf_render_bwd, so the all-reduce of those ranges runs while the rest still computes. */
+int cfnerf_grad_early_ranges(cfnerf_model* m, int64_t* offsets, int64_t* counts, int max_ranges);
+int cfnerf_stream_wait_grad_early(cfnerf_model* m, cfnerf_stream waiter);
+
 /* replaces: torch.optim.Adam.step() RUN:339,1067 on the flat buffers (betas .9/.999, eps 1e-8),
  * followed by the re-pack of cfnerf_model_set_params.  step is 1-based.  grad_scale multiplies
  * the gradient first (1/world_size after a sum all-reduce).                                      */

@@ -12,7 +12,8 @@ def trainer_rank(rank, world, port, q, spec):
     os.environ["MASTER_PORT"] = str(port)
     try:
         torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(spec.get("backend", "gloo"), rank=rank, world_size=world,
+                                **({"device_id": torch.device("cuda", 0)} if spec.get("backend") == "nccl" else {}))
         import cfnerf_amd                                      # noqa: F401
         from cfnerf_amd import train as TR
         from oracle import cfnerf_oracle as O
@@ -27,7 +28,8 @@ def trainer_rank(rank, world, port, q, spec):
         rays, (H, Wd, focal) = fern_rays(rng, N)
         target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
         lo, hi = TR.shard_bounds(N, rank, world)
-        tr = TR.Trainer(model, lrate=5e-4, lrate_decay=250, beta1=spec["beta1"], world_size=world)
+        tr = TR.Trainer(model, lrate=5e-4, lrate_decay=250, beta1=spec["beta1"], world_size=world, force_allreduce=spec.get("force", False),
+                        overlap_comm=spec.get("overlap", True))
         torch.manual_seed(1000 + rank)                        # DIFFERENT seeds per rank: the latents must still agree
         eps_used, losses = [], []
         for step in range(spec["steps"]):
@@ -42,8 +44,9 @@ def trainer_rank(rank, world, port, q, spec):
             sc = tr.step(H, Wd, focal, (rays[0, lo:hi].cuda(), rays[1, lo:hi].cuda()), target[lo:hi].cuda(), **kw)
             if not spec.get("explicit_eps"):
                 pass
-            s = sc[:2].clone().cpu()
+            s = sc[:2].clone() if spec.get("backend") == "nccl" else sc[:2].clone().cpu()
             dist.all_reduce(s)                                 # loss, nll: contributions sum to the global value
+            s = s.cpu()
             losses.append(s.numpy())
         torch.cuda.synchronize()
         q.put((rank, "ok", model.module.flat.detach().cpu().numpy(), np.array(losses), np.array(eps_used)))

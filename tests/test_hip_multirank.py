@@ -83,3 +83,18 @@ def test_two_ranks_on_the_product_path_match_the_single_process_full_batch(expli
     assert (d > 1e-6).mean() <= 1e-3, ((d > 1e-6).mean(), d.max())
     assert d.max() <= 3 * 2 * 5e-4 + 1e-6, d.max()
     np.testing.assert_allclose(losses0, losses_ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_exchange_path_on_one_rank_is_the_identity(overlap):
+    """The RCCL ("nccl") exchange of the product - with overlap: the early bucket gathered and all-reduced on a side stream
+    under the small-job launch (cfnerf_grad_early_ranges / cfnerf_stream_wait_grad_early), the late bucket after - on
+    a one-rank group, where a sum all-reduce changes nothing: the parameters after three steps equal those of the
+    plain single-process run bit for bit, so every element went through exactly one bucket and came back in place."""
+    spec = dict(W=64, K=4, N=64, seed=21, data_seed=5, beta1=0.01, steps=3, explicit_eps=True, backend="nccl", force=True, overlap=overlap)
+    got = _run_ranks(spec, world=1)
+    flat0, losses0, _ = got[0]
+    eps = [np.random.default_rng(7000 + s).standard_normal((spec["K"], 4)).astype(np.float32) for s in range(spec["steps"])]
+    flat_ref, losses_ref = _single_process(spec, eps)
+    assert np.array_equal(flat0, flat_ref)
+    np.testing.assert_allclose(losses0, losses_ref, rtol=0, atol=0)
