@@ -370,10 +370,12 @@ class NeRF_Flows(nn.Module):
         return self._eval_eps_dev
 
     def draw_eps(self):
-        """Fresh train latents in the reference's order: eps_alpha then eps_rgb (MOD:234,246)."""
+        """Fresh train latents in the reference's order: eps_alpha then eps_rgb (MOD:234,246), drawn from torch's CPU
+        generator like the reference.  The copy to the device goes through pinned memory and does not block the host
+        (a pageable copy would stall the launch queue every step)."""
         ea = torch.empty([self.K_samples, 1]).normal_()
         er = torch.empty([self.K_samples, 3]).normal_()
-        return torch.cat([er, ea], -1).to(self.device)
+        return torch.cat([er, ea], -1).pin_memory().to(self.device, non_blocking=True)
 
     # ---- forward (MOD:188-291) ---------------------------------------------------------------
     def forward(self, x, is_val=False, is_test=False, eps_alpha=None, eps_rgb=None):

@@ -68,7 +68,7 @@ class Trainer:
     identical seeding; step 0 uses one broadcast.  An explicit ``eps=`` argument overrides this (tests, benchmarks)."""
 
     def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False,
-                 overlap_comm=True):
+                 overlap_comm=False):
         self.force_allreduce = bool(force_allreduce)
         self.overlap_comm = bool(overlap_comm)
         self.net: NeRF_Flows = _unwrap(net)
@@ -113,10 +113,13 @@ class Trainer:
         return self._xplan
 
     def _exchange(self):
-        """Sum the gradient (and the latents tail) over the ranks.  With an RCCL group: two buckets - the early one is
-        gathered and all-reduced on a side stream as soon as its tensors are final, i.e. UNDER the small-job launch that
-        ends the backward; the late one (the small jobs' tensors, ~1/4 of the bytes) follows on the main stream.  A gloo
-        group (tests) or `overlap_comm=False`: one all-reduce of the whole buffer."""
+        """Sum the gradient (and the latents tail) over the ranks.  Default: ONE all-reduce of the whole flat buffer
+        (2.47 MB at W = 256).  `overlap_comm=True` (RCCL groups): two buckets - the early one (every bias, the base
+        Gaussians and the weights fed by the big dW launch alone: ~3/4 of the bytes) is gathered and all-reduced on a side
+        stream as soon as those tensors are final, i.e. UNDER the small-job launch that ends the backward (~0.23 ms);
+        the late one follows on the main stream.  On ONE GPU, where the exchange itself costs nothing, the gathers,
+        scatters and the second launch of the two-bucket form cost ~0.13 ms per step, more than a 2.5 MB all-reduce is
+        expected to expose on 8 GPUs - hence opt-in until it can be measured on a multi-GPU node."""
         import torch.distributed as dist
         if not self.overlap_comm or not self.gbuf.is_cuda or dist.get_backend(self.group) != "nccl":
             allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
@@ -157,7 +160,7 @@ class Trainer:
         K, n = self.net.K_samples, self.net.n_params
         tail = self.gbuf[n:n + 4 * K]
         if self.rank == 0:
-            tail.copy_(self.net.draw_eps().reshape(-1))
+            tail.copy_(self.net.draw_eps().reshape(-1))      # pinned, non-blocking: the host keeps running ahead
         else:
             tail.zero_()
 
