@@ -295,25 +295,28 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int n
         int nt = nt0 + j * nts;
         if (nt >= nt_total) nt = nt0 < nt_total ? nt0 : 0;      // clamped: value unused
         e.db[j] = dbp[nt * 32 + (lane & 31)];
-        e.mb[j] = (mbits != nullptr) ? mbits[nt * 64 + lane] : 0xffffffffu;
+        e.mb[j] = (mbits != nullptr) ? mbits[nt * 64 + lane] : 0xffffffffu;      // bit 31 - e: element e of the fragment
     }
 }
 
-// acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials
-// FULL: every row of the tile exists (the wave-uniform common case) - no per-element exec-mask code
-template <int NTW, int PREC, bool FULL>
-__device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
-                                               float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
-                                               int rows_valid) {
+// acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials.  The dY slab goes out through a buffer
+// descriptor over the tile's valid rows (scalar row offsets, ragged rows dropped by the bounds check: see slab_store);
+// the mask is applied with one v_bfe_i32 + one v_and per element (relu_bit_apply).
+template <int NTW, int PREC>
+__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                          int rows_valid) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, rows_valid, gld);
+    const bool full = rows_valid >= 64;               // wave-uniform
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = nt0 + j * nts;
         if (nt >= nt_total) continue;
         const int col = nt * 32 + (lane & 31);
         float* lp = lds_dst + rbase * ld + col;
-        float* gp = gdst + (size_t)rbase * gld + col;
+        const int voff = (rbase * gld + col) * 4;
         const uint32_t mb = e.mb[j];
         float csum = 0.f;
 #pragma unroll
@@ -321,24 +324,15 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = FULL || (rr + rbase < rows_valid);
-                const float v = (ok && ((mb >> (i * 16 + r)) & 1u)) ? acc[i][j][r] : 0.f;
+                float v = relu_bit_apply(mb, i * 16 + r, acc[i][j][r]);
+                if (!full && rr + rbase >= rows_valid) v = 0.f;        // rows past a ragged tile hold garbage activations
                 act_store<PREC>(lp + rr * ld, v);
-                if (FULL) st_stream(gp + (size_t)rr * gld, v);
-                else if (ok) st_stream(gp + (size_t)rr * gld, v);
+                slab_store(sink, voff, rr * gld * 4, v);
                 csum += v;
             }
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }
-}
-
-template <int NTW, int PREC>
-__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
-                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
-                                          int rows_valid) {
-    if (rows_valid >= 64) store_bwd_impl<NTW, PREC, true>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
-    else                  store_bwd_impl<NTW, PREC, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
 }
 
 template <int W, int PREC>

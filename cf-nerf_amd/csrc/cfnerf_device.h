@@ -275,11 +275,7 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     }
 }
 
-#ifdef CFN_EXP_NO_STASH_STORE
-__device__ __forceinline__ void st_stream(float* p, float v) { if (v == 1.2345e-30f) __builtin_nontemporal_store(v, p); }
-#else
 __device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
-#endif
 __device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
 
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
@@ -304,10 +300,33 @@ __device__ __forceinline__ void load_bias(const SubL s, int nt0, int nts, const 
 // (the compiler first quiets a possible signalling NaN of the MFMA result with max(x, x))
 __device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
+// A row-major [rows x ld] slab of a touch-once HBM stream (activation stash, pre-activation gradients) as a buffer
+// descriptor that covers exactly its valid rows: a lane keeps ONE byte offset (its first row and column), the row of
+// each fragment element is a SCALAR offset (rr * ld * 4: SALU, not VALU - on this chip every VALU instruction comes
+// out of the MFMA issue slots), and rows past the ragged end of the last tile fall outside the descriptor and are
+// dropped by the hardware bounds check, so there is no per-element exec-mask code either.  Non-temporal: the stream
+// must not evict the L2-resident packed weights.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(float* base, int rows_valid, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, rows_valid * ld * 4, 0x00020000);
+}
+__device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff_bytes, soff_bytes, /*nt*/ 2);
+}
+
+// ReLU mask of a lane's 32-row output fragment as ONE word, element e = i * 16 + r at bit 31 - e: built with one
+// v_sub + one v_alignbit per element (the sign bit of 0 - bits(v) is set iff v > 0 for a post-ReLU v), read back in
+// the backward with one v_bfe_i32 (sign-extended 1-bit field = all-ones / zero mask).
+__device__ __forceinline__ uint32_t relu_bit_push(uint32_t bits, float v_post_relu) {
+    return __builtin_amdgcn_alignbit(bits, (uint32_t)(0 - __float_as_int(v_post_relu)), 31);
+}
+__device__ __forceinline__ float relu_bit_apply(uint32_t bits, int e, float v) {
+    const int m = __builtin_amdgcn_sbfe((int)bits, 31 - e, 1);
+    return __int_as_float(__float_as_int(v) & m);
+}
+
 // epilogue of a layer: bias + activation -> LDS tile (and, in the train variants, the activation stash in HBM).
-// STASH is 0 (no stash code at all: the eval variants), 1 (stash every row: the wave-uniform common case of a full
-// tile) or 2 (ragged last tile: per-row check); store_tiles picks 1 / 2 / 0 from gdst and rows_valid once per call, so
-// the per-element work is add, max, ds_write (+ one non-temporal store) with no exec-mask juggling.
+// STASH is 0 (no stash code at all: the eval variants) or 1 (stash through a slab descriptor); store_tiles picks it
+// from gdst once per call, so the per-element work is max, ds_write (+ one buffer store, + two ops for the mask bit).
 template <int NTW, int ACT, int PREC, bool WANT_BITS, int STASH, bool BIAS_IN_ACC>
 __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                                  const float* __restrict__ wp, float* lds_dst, int ld, int col0,
@@ -315,6 +334,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                                                  uint32_t* __restrict__ mbits, const float* bias_pre) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, STASH ? rows_valid : 0, gld);      // unused (dead code) when STASH == 0
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = nt0 + j * nts;
@@ -322,7 +342,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
         const int col = nt * 32 + (lane & 31);
         const float bv = BIAS_IN_ACC ? 0.f : bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
         float* lp = lds_dst + rbase * ld + col0 + col;
-        float* gp = STASH ? gdst + (size_t)rbase * gld + col : nullptr;
+        const int voff = (rbase * gld + col) * 4;
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -332,11 +352,8 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 float v = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = relu_f(v);
                 act_store<PREC>(lp + rr * ld, v);
-                if (STASH == 1) st_stream(gp + rr * gld, v);
-                if (STASH == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * gld, v); }
-#ifndef CFN_EXP_NO_BITS
-                if (WANT_BITS) bits |= (v > 0.f ? 1u : 0u) << (i * 16 + r);
-#endif
+                if (STASH) slab_store(sink, voff, rr * gld * 4, v);
+                if (WANT_BITS) bits = relu_bit_push(bits, v);
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
@@ -349,12 +366,10 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const S
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                             float* __restrict__ gdst, int gld, int rows_valid,
                                             uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
-    if (MAY_STASH && gdst != nullptr) {
-        if (rows_valid >= 64) store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
-        else                  store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 2, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
-    } else {
+    if (MAY_STASH && gdst != nullptr)
+        store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+    else
         store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 0, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
-    }
 }
 
 // ---- elementwise numerics: the same definitions torch uses on the reference path ---------------
