@@ -288,6 +288,11 @@ def main():
                             "held to the same parity tolerances (tests/test_hip_bf16x3.py)",
                "value": wl.n * world * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
                "fwd_launch_ms": alt_fwd_ms, "fwd_fp32_equiv_tflops": wl.fwd_flops() / (alt_fwd_ms * 1e-3) / 1e12}
+        # its own roofline: three bf16 MFMAs per fp32 product on the 2.5 PFLOP/s dense bf16 matrix pipe
+        alt["roofline"] = {"bound": "mfma (bf16 pipe, 3 MFMAs per fp32 product)", "peak": 2500.0 / 3, "unit": "fp32-equivalent TFLOP/s",
+                           "achieved": alt["fwd_fp32_equiv_tflops"], "frac": alt["fwd_fp32_equiv_tflops"] / (2500.0 / 3),
+                           "note": "PMC: the matrix pipe is ~30 % busy in this mode - L2 weight streaming, LDS and the fp32 epilogues bound it "
+                                   "(profiles/r02_pmc_summary.txt, section pmc_b16)"}
 
     # SURVEY 8d "stress row": the authors' own recipe, next to the headline line (one GPU, default run only)
     stress = None
@@ -306,6 +311,32 @@ def main():
                   "step_frac_of_peak": 3 * fl / (dts / st_steps) / 1e12 / FP32_MFMA_PEAK_TF}
         ws.net.release_workspace()
         del ws
+
+    # the coarse + fine sampling EXTENSION (BASELINE configs 2/3/5 are worded "64 + 128"; the reference has no second pass, so
+    # this is NOT the parity path and never the headline): coarse 64 -> sample_pdf -> fine 64 + 128, both loss terms
+    hier = None
+    if world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32":
+        wh = Workload("C2", "train", rank, world, dev, "fp32", False)
+        sc = wh.sc
+
+        def hstep():
+            return wh.trainer.step_hierarchical(sc["H"], sc["W"], sc["focal"], wh.rays, wh.target, N_samples=64, N_importance=128, coarse_loss=True,
+                                                eps=torch.randn(wh.K, 4, device=dev, generator=wh.g), near=sc["near"], far=sc["far"], ndc=sc["ndc"])
+        for _ in range(3):
+            hstep()
+        sync()
+        h_steps = max(5, min(20, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(h_steps):
+            hstep()
+        sync()
+        dth = time.perf_counter() - t1
+        hier = {"workload": f"EXTENSION (not in the reference; parity unpinned): coarse 64 samples -> inverse-CDF resampling -> fine 64 + 128 samples "
+                            f"through the one network, coarse + fine KDE-NLL terms both differentiated; N_rand={wh.n}, K={wh.K}, W={wh.W}",
+                "value": wh.n * h_steps / dth, "unit": "rays/s", "ms_per_step": dth / h_steps * 1e3,
+                "points_per_ray": "64 (sampling pass) + 64 (coarse loss pass) + 192 (fine pass)"}
+        wh.net.release_workspace()
+        del wh
 
     out = None
     if rank == 0:
@@ -344,6 +375,8 @@ def main():
             out["alt_precision"] = alt
         if stress is not None:
             out["stress_w512"] = stress
+        if hier is not None:
+            out["alt_config"] = hier
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode, wl.cfg)
 

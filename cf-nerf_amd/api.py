@@ -764,6 +764,36 @@ def save_checkpoint(path, global_step, network_fn, optimizer=None, trainer=None)
     return path
 
 
+def _checkpoint_to_reload(args):
+    """The checkpoint create_nerf() resumes from, by the reference's rules (RUN:345-357): an explicit ``ft_path`` wins;
+    otherwise the log directory ``basedir/dataname/type_flows/expname`` is searched for ``*tar*`` files and either the
+    newest one (``index_step == -1``) or ``<index_step>_01.tar`` is taken.  ``no_reload`` disables all of it."""
+    if getattr(args, "no_reload", False):
+        return None
+    ft = getattr(args, "ft_path", None)
+    logdir = os.path.join(args.basedir, args.dataname, args.type_flows, args.expname)
+    found = [ft] if ft is not None and ft != 'None' else (
+        [os.path.join(logdir, f) for f in sorted(os.listdir(logdir)) if 'tar' in f] if os.path.isdir(logdir) else [])
+    if not found:
+        return None
+    return found[-1] if args.index_step == -1 else os.path.join(logdir, '{:06d}_{:02d}.tar'.format(args.index_step, 1))
+
+
+def _maybe_reload(args, model) -> int:
+    """Load network weights from a reference-format checkpoint (RUN:358-378): keys the model does not have are dropped,
+    the optimiser state is NOT restored (that line is commented out in the reference).  Returns the global step."""
+    path = _checkpoint_to_reload(args)
+    if path is None:
+        print('No reloading')
+        return 0
+    print('Reloading from', path)
+    ckpt = torch.load(path, map_location="cpu")
+    own = model.state_dict()
+    own.update({k: v for k, v in ckpt['network_fn_state_dict'].items() if k in own})
+    model.load_state_dict(own)
+    return ckpt['global_step']
+
+
 def create_nerf(args):
     """Instantiate the CF-NeRF model (RUN:317-409).  Returns
     ``(render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)``."""
@@ -785,32 +815,7 @@ def create_nerf(args):
     network_query_fn._cfnerf_fused = True        # render_rays may replace query + composite by the fused launch
 
     optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
-    start = 0
-
-    # checkpoints (RUN:345-378): newest '*tar*' in the log dir unless ft_path is given; keys filtered
-    # to those the model has; the optimiser state is NOT restored (commented out in the reference).
-    ckpts = []
-    if getattr(args, "ft_path", None) is not None and args.ft_path != 'None':
-        ckpts = [args.ft_path]
-    else:
-        d = os.path.join(args.basedir, args.dataname, args.type_flows, args.expname)
-        if os.path.isdir(d):
-            ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f]
-    if len(ckpts) > 0 and not args.no_reload:
-        if args.index_step == -1:
-            ckpt_path = ckpts[-1]
-        else:
-            ckpt_path = os.path.join(args.basedir, args.dataname, args.type_flows, args.expname,
-                                     '{:06d}_{:02d}.tar'.format(args.index_step, 1))
-        print('Reloading from', ckpt_path)
-        ckpt = torch.load(ckpt_path, map_location="cpu")
-        start = ckpt['global_step']
-        model_dict = model.state_dict()
-        pretrained = {k: v for k, v in ckpt['network_fn_state_dict'].items() if k in model_dict}
-        model_dict.update(pretrained)
-        model.load_state_dict(model_dict)
-    else:
-        print('No reloading')
+    start = _maybe_reload(args, model)
 
     render_kwargs_train = {
         'is_train': args.is_train, 'uniformsample': args.uniformsample, 'network_query_fn': network_query_fn,
