@@ -51,6 +51,7 @@ static int model_init_device(cfnerf_model* m) {
     HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
     m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
     HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
+    HIPCHK(hipMalloc(&m->d_enc_scratch, (size_t)m->ent_cap * kTileM * 64 * sizeof(float)));
     HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
     for (int i = 0; i < kNumTimers; ++i) {
         HIPCHK(hipEventCreate(&m->ev0[i]));
@@ -161,6 +162,7 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     if (!m) return CFNERF_OK;
     hipDeviceSynchronize();
     hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
+    hipFree(m->d_enc_scratch);
     hipFree(m->d_eps);
     m->stash.release();
     m->bwd.release();
@@ -242,6 +244,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
     a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt; a.kstats = kstats_opt;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
+    a.enc_scratch = m->d_enc_scratch;
     if ((flags & CFNERF_F_STASH) && !maps) return fail(CFNERF_E_INVALID, "STASH needs the per-K maps");
     if (flags & CFNERF_F_STASH) {
         char why[256];

@@ -193,11 +193,25 @@ void fused_fwd_kernel(const FwdArgs A) {
             CFN_MARK();                              // sampling done
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
-            if (A.st_enc != nullptr) {
+            // gamma(p) is needed again at the skip layer, five layers later, when the in-place tile has long been overwritten.
+            // Re-evaluating it there cost ~800 vector instructions per wave and tile (30 correctly rounded sincosf per point);
+            // instead the tile is parked as 16 KB of row-major fp32 - in the activation stash when there is one (the backward
+            // wants it there anyway), else in this workgroup's slot of a small L2-resident scratch - and fetched back with
+            // four 16-byte loads per thread.
+            float* enc_park = (MODE == 0) ? (A.st_enc != nullptr ? A.st_enc + p0 * 64 : A.enc_scratch + (size_t)blockIdx.x * (kTileM * 64)) : nullptr;
+            if (MODE == 0 || A.st_enc != nullptr) {
                 __syncthreads();
-                for (int idx = tid; idx < kTileM * 64; idx += kThr) {
-                    const int row = idx >> 6, c = idx & 63;
-                    if (row < rows_valid) st_stream(A.st_enc + (p0 + row) * 64 + c, act_load<PREC>(act + row * LD + c));
+                float* dst = (MODE == 0) ? enc_park : A.st_enc + p0 * 64;
+                for (int idx = tid; idx < kTileM * 16; idx += kThr) {
+                    const int row = idx >> 4, q = idx & 15;
+                    if (row < rows_valid) {
+                        f32x4 v;
+                        const float* src = act + row * LD + 4 * q;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = act_load<PREC>(src + c);
+                        if (A.st_enc != nullptr) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + row * 64 + 4 * q));
+                        else *reinterpret_cast<f32x4*>(dst + row * 64 + 4 * q) = v;
+                    }
                 }
             }
             __syncthreads();
@@ -214,7 +228,19 @@ void fused_fwd_kernel(const FwdArgs A) {
                 CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
-                    encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);   // act[:, 0:64) <- gamma(p) again
+                    if (MODE == 0) {                 // act[:, 0:64) <- gamma(p) again, from where the tile was parked
+                        for (int idx = tid; idx < kTileM * 16; idx += kThr) {
+                            const int row = idx >> 4, q = idx & 15;
+                            f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;           // rows past a ragged tile: finite filler
+                            // nt load: served by L2, never by this CU's L1 (the scratch slot is rewritten every tile)
+                            if (row < rows_valid) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(enc_park + row * 64 + 4 * q));
+                            float* dstl = act + row * LD + 4 * q;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) act_store<PREC>(dstl + c, v[c]);
+                        }
+                    } else {
+                        encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
+                    }
                     __syncthreads();
                     mma_any<C::NTW, PREC, 2>(acc, T.skipseg, wave, kWv, wp, wp16, act, LD);
                 }

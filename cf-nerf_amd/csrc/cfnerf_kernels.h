@@ -28,6 +28,7 @@ struct FwdArgs {
     float *raw, *weights, *pts;          // optional [P,K,4] [P,K] [P,3]
     float *kstats;                       // optional [N,8] fused K-statistics
     float* ent_partials;                 // [grid,2]  (TRAIN)
+    float* enc_scratch;                  // [grid, 64*64] per-workgroup parking slot of the encoded tile (used when there is no stash)
     // activation stash for the backward pass (all optional, row-major per point)
     float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
     float *st_at;                        // [P,K,2] alpha, transmittance T of the composite

@@ -117,6 +117,7 @@ struct cfnerf_model {
     cfnerf::PackDesc* d_descs = nullptr;
     const float* flat = nullptr;          // caller-owned flat parameter buffer (last set_params)
     float* d_ent_partials = nullptr; int ent_cap = 0;
+    float* d_enc_scratch = nullptr;       // [ent_cap, 64*64] forward scratch: one encoded tile per resident workgroup (8 MB, L2-resident)
     float* d_eps = nullptr;               // eps of the stashed forward
     cfnerf::Stash stash;
     cfnerf::BwdPlan bwd;
