@@ -240,8 +240,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CFNERF_BENCH_SAME_GPU=1 (testing the N > 1 code path on a one-GPU box): every rank uses cuda:0 and the ranks talk over gloo
+    same_gpu = os.environ.get("CFNERF_BENCH_SAME_GPU") == "1"
+    dev_index = 0 if same_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dist = os.environ.get("CFNERF_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (tests)
     dist = None
     if world > 1 or force_dist:
@@ -250,7 +253,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if force_dist and "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from cfnerf_amd import train as T
     if not T.backward_available():
@@ -267,7 +273,7 @@ def main():
     def max_over_ranks(dt):
         if dist is None:
             return dt
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if same_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 

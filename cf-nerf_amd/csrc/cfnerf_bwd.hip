@@ -4,11 +4,15 @@
 // Reference lines replaced: loss RUN:1026-1050; loss.backward() RUN:1066 (autograd of RUN:411-454,
 // MOD:188-291, FLW:225-268); Adam RUN:339,1067.
 //
-// Data flow of cfnerf_render_bwd (activations come from the CFNERF_F_STASH forward):
-//   tail_bwd_kernel   d_rgb_map/d_depth/d_entropy + raw, alpha, T, theta  -> g_theta [P,128] (+ base-Gaussian partials)
-//   bwd_data_kernel   g_theta -> g_hr, g_ha, g_v, g_feat, g_h[D-1..0]      (same LDS-tile / MFMA structure as forward)
-//   dw_kernel         dW = dY^T X per layer, split over P, fp32 MFMA, operands straight from HBM/L2
-//   reduce kernels    partial sums -> grad_flat (deterministic: no float atomics anywhere)
+// Data flow of cfnerf_render_bwd (activations come from the CFNERF_F_STASH forward; everything lives in the workspace):
+//   tail_bwd_kernel    d_rgb_map/d_depth/d_entropy + raw, alpha, T, theta -> g_theta [parts][P,128] (+ base-Gaussian partials)
+//   reduce_gms         -> grad of alpha_mean/std, rgb_mean/std
+//   bwd_data_kernel    sum of the g_theta parts -> g_hr, g_ha, g_v, g_feat, g_h[D-1..0]  (same LDS-tile / MFMA structure as forward)
+//   reduce_bias        per-workgroup bias partials -> every bias gradient
+//   dw_big_kernel      dW = dY^T X for the >= 128 x 128 jobs: ONE launch, 2 x 4 and 1 x 8 wave arrangements, split over P
+//   reduce_weights(1)  tensors fed by the big launch alone -> grad_flat; ev_early recorded (cfnerf_stream_wait_grad_early)
+//   dw_small_kernel    encodings / heads / flow heads
+//   reduce_weights(0)  the remaining tensors -> grad_flat        (deterministic throughout: no float atomics anywhere)
 #include "cfnerf_device.h"
 #include "cfnerf_kernels.h"
 #include "cfnerf_model.h"
