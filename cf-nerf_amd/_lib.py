@@ -32,6 +32,7 @@ _SIGS = {
     "cfnerf_sample_points": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "cfnerf_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P]),
+    "cfnerf_render_eval": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "cfnerf_sample_pdf": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
     "cfnerf_network_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
     "cfnerf_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

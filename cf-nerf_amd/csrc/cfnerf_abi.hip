@@ -272,6 +272,28 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     return CFNERF_OK;
 }
 
+int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, const float* eps, int64_t N, int S, int K, int flags,
+                       const float* gt_opt, float* kstats, float* sqerr_opt, cfnerf_stream s) {
+    if (int rc = check_common(m, K)) return rc;
+    if (N < 0 || S < 1) return fail(CFNERF_E_INVALID, "bad N/S");
+    if (N == 0) return CFNERF_OK;
+    if (!rays || !eps || !t_vals || !kstats) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (K < 2) return fail(CFNERF_E_INVALID, "kstats needs K >= 2 (std * n/(n-1))");
+    if ((gt_opt == nullptr) != (sqerr_opt == nullptr)) return fail(CFNERF_E_INVALID, "gt_opt and sqerr_opt must be given together");
+    if (flags & (CFNERF_F_TRAIN | CFNERF_F_STASH)) return fail(CFNERF_E_INVALID, "cfnerf_render_eval is the eval branch only");
+    FwdArgs a{};
+    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
+    a.rays = rays; a.t_vals = t_vals; a.eps = eps;
+    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
+    a.kstats = kstats; a.gt = gt_opt; a.sqerr = sqerr_opt; a.enc_scratch = m->d_enc_scratch;
+    int grid = 0;
+    hipStream_t st = (hipStream_t)s;
+    if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
+    HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, false, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
+    if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
+    return CFNERF_OK;
+}
+
 int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* weights, const float* u,
                       int64_t N, int S, int K, int N_importance, float* z_out, cfnerf_stream s) {
     if (N < 0 || S < 3 || K < 1 || N_importance < 1) return fail(CFNERF_E_INVALID, "bad N/S/K/N_importance (S >= 3)");

@@ -475,6 +475,10 @@ void fused_fwd_kernel(const FwdArgs A) {
                     for (int k = 0; k < K; ++k) { const float d = comp[k * 8 + c] - mean; var += d * d; }
                     o[tid] = mean;
                     o[3 + tid] = sqrtf(var / (float)K) * (float)K / (float)(K - 1);
+                    if (A.sqerr != nullptr) {                                  // the integrand of img2mse(rgb_mean, target), RUN:1028 / HLP:15
+                        const float e = mean - A.gt[unit * 3 + tid];
+                        A.sqerr[unit * 3 + tid] = e * e;
+                    }
                 } else {
                     o[6 + (tid - 3)] = mean;
                 }

@@ -27,6 +27,8 @@ struct FwdArgs {
     float *rgb_map, *disp, *depth;       // [N,3,K] [N,K] [N,K]
     float *raw, *weights, *pts;          // optional [P,K,4] [P,K] [P,3]
     float *kstats;                       // optional [N,8] fused K-statistics
+    const float* gt;                     // optional [N,3] ground-truth colours (eval): with kstats, sqerr is written
+    float* sqerr;                        // optional [N,3] (K-mean rgb - gt)^2 per pixel and channel
     float* ent_partials;                 // [grid,2]  (TRAIN)
     float* enc_scratch;                  // [grid, 64*64] per-workgroup parking slot of the encoded tile (used when there is no stash)
     // activation stash for the backward pass (all optional, row-major per point)

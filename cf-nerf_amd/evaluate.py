@@ -43,11 +43,13 @@ def row_shard(H: int, rank: int, world: int):
 
 @torch.no_grad()
 def render_uncertainty(H, W, focal, c2w, network_fn, near=0., far=1., ndc=True, lindisp=False, white_bkgd=False,
-                       rows=None, want_maps=False, t_vals=None, **_ignored):
+                       rows=None, want_maps=False, t_vals=None, gt=None, **_ignored):
     """Eval render of rows ``rows=(r0, r1)`` (default: all) of the image seen from ``c2w`` with the reductions over the
     K latent samples fused into the kernel.  Returns a dict with ``rgb_mean [h,W,3]``, ``rgb_unc [h,W,3]``
     (= ``np.std(rgbs,-1) * n/(n-1)``, RUN:1129-1130), ``disp_mean [h,W]`` (RUN:1124), ``depth_mean [h,W]`` and, if
-    ``want_maps``, the per-K ``rgb_map [h,W,3,K]``, ``disp_map``, ``depth_map`` as render() returns them."""
+    ``want_maps``, the per-K ``rgb_map [h,W,3,K]``, ``disp_map``, ``depth_map`` as render() returns them.  With ``gt``
+    (ground-truth colours of those rows, ``[h,W,3]``) the per-pixel squared error of the K-mean prediction is produced by the
+    same launch (``sq_err [h,W,3]``; ``mse`` = its mean = ``img2mse(rgb_mean, gt)``, RUN:1028)."""
     net = _unwrap(network_fn)
     dev = net.device
     r0, r1 = rows if rows is not None else (0, H)
@@ -69,13 +71,26 @@ def render_uncertainty(H, W, focal, c2w, network_fn, near=0., far=1., ndc=True, 
     rgb = disp = depth = None
     if want_maps:
         rgb, disp, depth = torch.empty(n, 3, K, device=dev), torch.empty(n, K, device=dev), torch.empty(n, K, device=dev)
-    L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(packed), L.ptr(t_vals), None, None, L.ptr(eps), n, S, K, flags, L.ptr(rgb), L.ptr(disp),
-                                  L.ptr(depth), None, None, None, L.ptr(kst), None, L.stream()), "cfnerf_render_fwd")
+    sq = None
+    if want_maps:
+        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(packed), L.ptr(t_vals), None, None, L.ptr(eps), n, S, K, flags, L.ptr(rgb), L.ptr(disp),
+                                      L.ptr(depth), None, None, None, L.ptr(kst), None, L.stream()), "cfnerf_render_fwd")
+        if gt is not None:
+            sq = (kst[:, 0:3] - gt.to(dev, torch.float32).reshape(n, 3)) ** 2
+    else:
+        g = None
+        if gt is not None:
+            g = gt.to(dev, torch.float32).reshape(n, 3).contiguous()
+            sq = torch.empty(n, 3, device=dev)
+        L.check(lib.cfnerf_render_eval(net.handle, L.ptr(packed), L.ptr(t_vals), L.ptr(eps), n, S, K, flags, L.ptr(g), L.ptr(kst), L.ptr(sq),
+                                       L.stream()), "cfnerf_render_eval")
     h = r1 - r0
     out = dict(rgb_mean=kst[:, 0:3].reshape(h, W, 3), rgb_unc=kst[:, 3:6].reshape(h, W, 3), disp_mean=kst[:, 6].reshape(h, W),
                depth_mean=kst[:, 7].reshape(h, W))
     if want_maps:
         out.update(rgb_map=rgb.reshape(h, W, 3, K), disp_map=disp.reshape(h, W, K), depth_map=depth.reshape(h, W, K))
+    if sq is not None:
+        out.update(sq_err=sq.reshape(h, W, 3), mse=sq.mean())
     return out
 
 

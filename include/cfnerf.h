@@ -128,6 +128,14 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
                       float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out,
                       cfnerf_stream s);
 
+/* replaces: what the training loop's evaluation block derives from a full-image render (render_path_train RUN:247-314 with
+ * RUN:1117-1131: K-mean prediction, np.std * n/(n-1) uncertainty, mean disparity / depth) and the per-pixel integrand of
+ * img2mse(rgb_mean, target) (RUN:1028, HLP:15), all reduced INSIDE the fused forward: only 32 (+12) bytes per pixel leave
+ * the chip instead of 20*K.  Eval branch (fixed eps, no jitter).  kstats [N,8] as in cfnerf_render_fwd; gt_opt [N,3] and
+ * sqerr_opt [N,3] = (K-mean rgb - gt)^2 go together or are both NULL.                                                  */
+int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, const float* eps, int64_t N, int S, int K,
+                       int flags, const float* gt_opt, float* kstats, float* sqerr_opt, cfnerf_stream s);
+
 /* EXTENSION (not in the reference, whose N_importance / network_fine are dead parameters, RUN:467-468; the
  * semantics restated are those of the reference's upstream, yenchenlin/nerf-pytorch sample_pdf): inverse-CDF
  * resampling of N_importance depths per ray from the K-mean of the coarse weights, merged and sorted with the

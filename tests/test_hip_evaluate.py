@@ -60,6 +60,16 @@ def test_fused_uncertainty_maps_match_the_per_k_maps(white_bkgd, ndc, K):
     parts = [E.render_uncertainty(H, W, focal, c2w, model, rows=E.row_shard(H, rk, 3), **kw) for rk in range(3)]
     assert torch.equal(torch.cat([q["rgb_mean"] for q in parts], 0), full["rgb_mean"])
     assert torch.equal(torch.cat([q["rgb_unc"] for q in parts], 0), full["rgb_unc"])
+    # per-pixel squared error of the K-mean prediction (the integrand of img2mse(rgb_mean, target), RUN:1028) from the same
+    # launch (cfnerf_render_eval): equals the torch expression on the fused means, also on a row shard
+    gt = torch.tensor(np.random.default_rng(3).uniform(0, 1, (H, W, 3)), dtype=torch.float32)
+    fe = E.render_uncertainty(H, W, focal, c2w, model, gt=gt, **kw)
+    assert torch.equal(fe["rgb_mean"], full["rgb_mean"])
+    close(fe["sq_err"], ((full["rgb_mean"].cpu() - gt) ** 2).numpy(), atol=1e-7, rtol=1e-6, what="sq_err")
+    close(fe["mse"], cfnerf_amd.img2mse(full["rgb_mean"].cpu(), gt), atol=1e-7, rtol=1e-5, what="mse")
+    r0, r1 = E.row_shard(H, 1, 3)
+    fs = E.render_uncertainty(H, W, focal, c2w, model, gt=gt[r0:r1], rows=(r0, r1), **kw)
+    assert torch.equal(fs["sq_err"], fe["sq_err"][r0:r1])
     # and against the CPU oracle
     ea, er = net.sample_alpha.clone(), net.sample_rgb.clone()
     ea[-1] = 0
