@@ -126,10 +126,11 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int
         if (nt >= (int)s.nt) nt = nt0;          // never dereferenced (j >= nvalid)
         bp[j] = reinterpret_cast<const f32x4*>(wp + s.w_off) + (size_t)nt * KC * 64 + lane;
     }
-    if (nvalid == NTW) { mma_loop<NTW, NTW>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 1 && nvalid == 1) { mma_loop<NTW, 1>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 2 && nvalid == 2) { mma_loop<NTW, (NTW > 2 ? 2 : 1)>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 3 && nvalid == 3) { mma_loop<NTW, (NTW > 3 ? 3 : 1)>(acc, bp, a_ptr, lda, KC); return; }
+    // Every operand of the supported widths (64 / 128 / 256 / 512, heads of 32 / 64 / 96 columns) gives a wave either all
+    // NTW of its n-tiles or none (NT is a multiple of the wave count or smaller than it): ONE loop variant per call site, so the
+    // accumulators stay in place (a set of partial variants made the compiler shuffle 32 accumulator registers through
+    // v_mov_b64 around every GEMM segment).
+    mma_loop<NTW, NTW>(acc, bp, a_ptr, lda, KC);
 }
 
 // ================= opt-in split-bf16 ("bf16x3") operand path =====================================
@@ -239,10 +240,7 @@ __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, i
         if (nt >= (int)s.nt) nt = nt0;
         bp[j] = reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + (size_t)nt * KC * 128 + lane;
     }
-    if (nvalid == NTW) { mma_loop16<NTW, NTW, PRE>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 1 && nvalid == 1) { mma_loop16<NTW, 1, PRE>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 2 && nvalid == 2) { mma_loop16<NTW, (NTW > 2 ? 2 : 1), PRE>(acc, bp, a_ptr, lda, KC); return; }
-    if (NTW > 3 && nvalid == 3) { mma_loop16<NTW, (NTW > 3 ? 3 : 1), PRE>(acc, bp, a_ptr, lda, KC); return; }
+    mma_loop16<NTW, NTW, PRE>(acc, bp, a_ptr, lda, KC);        // all or none of a wave's n-tiles exist: see mma_seg
 }
 
 // precision-dispatching wrapper used by the fused kernels
