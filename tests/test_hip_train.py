@@ -338,6 +338,49 @@ def test_full_size_train_step_properties(tag, N, K, ndc):
     model.module.release_workspace()
 
 
+def test_large_batch_past_2G_stash_elements():
+    """Maximum-size case: 12 288 rays x 128 samples at W = 256 = 1.57 M points, i.e. 3.2e9 stashed trunk activations
+    (> 2^31 elements, 12.9 GB for that array alone; 38 GB workspace) - three times the largest BASELINE train batch.  Every
+    per-point offset in the kernels has to be 64-bit for this to work.  Checked against what the C3-size launches
+    (validated above) produce: the per-ray maps of the big launch are bit-identical to those of its three 4096-ray
+    thirds, and the thirds' gradients (world_size = 3 semantics) sum to the big one."""
+    N, K, W_ = 12288, 4, 256
+    cfg = O.OracleCfg(netwidth=W_, K_samples=K)
+    _, _, _, model, p, _ = build_model(cfg, 3)
+    import ctypes as C
+    from cfnerf_amd import _lib as L
+    need = L.lib().cfnerf_workspace_bytes(C.byref(model.module.cfg), N, 128, K)
+    free, _total = torch.cuda.mem_get_info()
+    if free < need + (8 << 30):
+        pytest.skip(f"needs {need >> 30} GiB of workspace, {free >> 30} GiB free")
+    assert N * 128 * W_ * 8 > 2 ** 31
+    rng = np.random.default_rng(23)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    rays = rays.to(DEV)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32, device=DEV)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32, device=DEV)
+    eps = torch.tensor(rng.standard_normal((K, 4)), dtype=torch.float32, device=DEV)
+
+    def grad(lo, hi, world):
+        tr = TR.Trainer(model, beta1=0.01, world_size=world)
+        g = tr.forward_backward(H, Wd, focal, (rays[0, lo:hi], rays[1, lo:hi]), target[lo:hi], t_rand=t_rand[lo:hi], eps=eps)
+        return g.clone(), tr.scalars.clone(), tr.rgb_map.clone(), tr.depth.clone()
+
+    g, s, rgb, depth = grad(0, N, 1)
+    assert torch.isfinite(g).all() and torch.isfinite(s).all() and float(g.abs().max()) > 0
+    g_sum, s_sum = torch.zeros_like(g), torch.zeros(2, device=DEV)
+    for i in range(3):
+        lo, hi = i * N // 3, (i + 1) * N // 3
+        gi, si, rgb_i, depth_i = grad(lo, hi, 3)
+        assert torch.equal(rgb_i, rgb[lo:hi]) and torch.equal(depth_i, depth[lo:hi]), f"maps of third {i} differ from the big launch"
+        g_sum += gi
+        s_sum += si[:2]
+    scale = float(g.abs().max())
+    assert float((g_sum - g).abs().max()) <= 2e-5 * scale, float((g_sum - g).abs().max()) / scale
+    close(s_sum.cpu(), s[:2].cpu(), atol=1e-5, rtol=1e-5, what="loss, nll: sums over thirds")
+    model.module.release_workspace()
+
+
 def test_stale_stash_is_refused_and_workspace_contract():
     """One stash per model: a backward whose forward has been overwritten by a later grad-enabled forward fails loudly
     (it used to differentiate the wrong batch silently).  And the ownership contract of the C ABI: with a caller-owned
