@@ -350,11 +350,10 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
 
 template <int W, int PREC>
 __global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
-void bwd_data_kernel(const BwdArgs A) {
+void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scalar loads from the kernarg segment (see fused_fwd_kernel)
     constexpr int LD = act_ld(W);
     constexpr int NT = W / 32, NTW = (NT + kWaves - 1) / kWaves, NTV = (W / 64 + kWaves - 1) / kWaves;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const NetTab& T = *A.tab;
     const int HA = T.ha_sz, HR = T.hr_sz, HLD = HA + 4, D = T.D;
     float* act = smem;
     float* hs = act + kTileM * LD;
@@ -941,7 +940,7 @@ static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, 
     if (!fn) return hipErrorInvalidValue;
     int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)a.n_wg);
     if (grid_out) *grid_out = grid;
-    void* args[] = {const_cast<BwdArgs*>(&a)};
+    void* args[] = {const_cast<BwdArgs*>(&a), const_cast<NetTab*>(&ht)};
     return hipLaunchKernel(fn, dim3(grid), dim3(kThreads), args, lds, st);
 }
 

@@ -87,12 +87,14 @@ extern "C" int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
 
 template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
 __global__ __launch_bounds__(FwdCfg<W>::NTHR, 2)
-void fused_fwd_kernel(const FwdArgs A) {
+void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
+    // T by value: it lives in the kernarg segment, so every per-layer descriptor read is a scalar load from constant
+    // memory.  Through a global pointer the compiler must assume the kernel's own stores may alias it and issues VECTOR
+    // loads with a full wait in front of each layer's first operand fetch (two or three dependent L2 round trips).
     using C = FwdCfg<W>;
     constexpr int LD = C::LD;
     constexpr int kWv = C::NWV, kThr = C::NTHR;     // waves / threads of this width's workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const NetTab& T = *A.tab;
     const int HA = T.ha_sz, HR = T.hr_sz;
     const int HLD = HA + 4;
     float* act = smem;
@@ -191,6 +193,11 @@ void fused_fwd_kernel(const FwdArgs A) {
             }
 
             CFN_MARK();                              // sampling done
+            // Biases are fetched ONE PHASE AHEAD of the accumulator initialisation that needs them (the accumulators must
+            // hold them before a layer's first MFMA, so a fetch at the top of the layer is an exposed L2 round trip per layer):
+            // layer 0's rides under the encoding, layer l+1's under layer l's MFMAs, and so on down the heads.
+            float bias_n[C::NTW];
+            load_bias<C::NTW>(T.trunk[0], wave, kWv, wp, bias_n);
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             // gamma(p) is needed again at the skip layer, five layers later, when the in-place tile has long been overwritten.
@@ -220,9 +227,8 @@ void fused_fwd_kernel(const FwdArgs A) {
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
             for (int l = 0; l < T.D; ++l) {
                 f32x16 acc[2][C::NTW];
-                float bias[C::NTW];
-                load_bias<C::NTW>(T.trunk[l], wave, kWv, wp, bias);
-                acc_init(acc, bias);
+                acc_init(acc, bias_n);
+                load_bias<C::NTW>((l + 1 < T.D) ? T.trunk[l + 1] : T.ft, wave, kWv, wp, bias_n);     // next layer's / the feature head's
                 CFN_MARK();                          // MFMA phase of layer l starts
                 mma_any<C::NTW, PREC, 2>(acc, T.trunk[l], wave, kWv, wp, wp16, act, LD);
                 CFN_MARK();                          // ... ends for wave 0
@@ -257,12 +263,12 @@ void fused_fwd_kernel(const FwdArgs A) {
             // ---- 4. heads: h_alpha = A h (MOD:175), feature = F h (MOD:176).  h_alpha is only 1-2 n-tiles wide: its K is
             //         split over the 4 waves (a quarter or half each) and the partial tiles are summed through act[] once
             //         h is dead, instead of one wave grinding through the whole K while three wait.
+            float bias_v[C::NTV];                    // views-layer bias, in flight during the heads
             {
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
-                float biasF[C::NTW];
-                load_bias<C::NTW>(T.ft, wave, kWv, wp, biasF);
-                acc_init(accF, biasF); acc_zero(accA);
+                acc_init(accF, bias_n); acc_zero(accA);
+                load_bias<C::NTV>(T.vf, wave, kWv, wp, bias_v);
                 mma_ksplit<PREC, 2>(accA, T.ha, wave, kWv, wp, wp16, act, LD);
                 mma_any<C::NTW, PREC, 2>(accF, T.ft, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
@@ -294,11 +300,11 @@ void fused_fwd_kernel(const FwdArgs A) {
             }
             CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
+            float bias_h[1];                         // h_rgb bias, in flight during the views layer
             {
                 f32x16 acc[2][C::NTV];
-                float bias[C::NTV];
-                load_bias<C::NTV>(T.vf, wave, kWv, wp, bias);
-                acc_init(acc, bias);
+                acc_init(acc, bias_v);
+                load_bias<1>(T.hr, wave, kWv, wp, bias_h);
                 mma_any<C::NTV, PREC, 2>(acc, T.vf, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThr) {
@@ -321,9 +327,7 @@ void fused_fwd_kernel(const FwdArgs A) {
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 f32x16 acc[2][1];
-                float bias[1];
-                load_bias<1>(T.hr, wave, kWv, wp, bias);
-                acc_init(acc, bias);
+                acc_init(acc, bias_h);
                 mma_any<1, PREC, 2>(acc, T.hr, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, T.hr, wave, kWv, wp, act, LD, W / 2,
@@ -338,6 +342,7 @@ void fused_fwd_kernel(const FwdArgs A) {
                 acc_zero(acc);
                 const bool is_rgb = wave < 3;               // waves 0-2: the three rgb n-tiles; wave 3: alpha; others idle
                 const bool is_theta = wave < 4;
+                const float bv = wp[(is_rgb ? T.fr.b_off + wave * 32 : T.fa.b_off) + (lane_id_opaque() & 31)];   // lands under the MFMAs
                 if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act + W / 2, LD);
                 else if (is_theta) mma_any<1, PREC, 2>(acc, T.fa, 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
@@ -347,7 +352,6 @@ void fused_fwd_kernel(const FwdArgs A) {
                 const int lo = lane_id_opaque();
                 const int cl = lo & 31, rbase = 4 * (lo >> 5);
                 const int c_local = is_rgb ? colb + cl : cl;          // column inside the rgb / alpha head block
-                const float bv = wp[s.b_off + nt * 32 + cl];
                 const int F = 4;
                 const bool tanh_col = is_rgb ? (c_local >= 9 * F && c_local < 15 * F) : (c_local < 2 * F);
                 float* lp = act + rbase * LD + colb + cl;
@@ -797,7 +801,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, int
     int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(FwdCfg<W>::NTHR), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(FwdCfg<W>::NTHR), lds, st, a, ht);
     return hipGetLastError();
 }
 
