@@ -340,7 +340,7 @@ def main():
         hier = {"workload": f"EXTENSION (not in the reference; parity unpinned): coarse 64 samples -> inverse-CDF resampling -> fine 64 + 128 samples "
                             f"through the one network, coarse + fine KDE-NLL terms both differentiated; N_rand={wh.n}, K={wh.K}, W={wh.W}",
                 "value": wh.n * h_steps / dth, "unit": "rays/s", "ms_per_step": dth / h_steps * 1e3,
-                "points_per_ray": "64 (sampling pass) + 64 (coarse loss pass) + 192 (fine pass)"}
+                "points_per_ray": "64 (coarse pass: sampling weights + its loss term) + 192 (fine pass)"}
         wh.net.release_workspace()
         del wh
 

@@ -45,8 +45,6 @@ static int model_init_device(cfnerf_model* m) {
     HIPCHK(hipMemset(m->d_packed, 0, pbytes));
     HIPCHK(hipMalloc(&m->d_packed16, (size_t)m->plan.tab.packed16_elems * 2));
     HIPCHK(hipMemset(m->d_packed16, 0, (size_t)m->plan.tab.packed16_elems * 2));
-    HIPCHK(hipMalloc(&m->d_tab, sizeof(NetTab)));
-    HIPCHK(hipMemcpy(m->d_tab, &m->plan.tab, sizeof(NetTab), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
     HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
     m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
@@ -161,7 +159,7 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
 int cfnerf_model_destroy(cfnerf_model* m) {
     if (!m) return CFNERF_OK;
     hipDeviceSynchronize();
-    hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_tab); hipFree(m->d_descs); hipFree(m->d_ent_partials);
+    hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_descs); hipFree(m->d_ent_partials);
     hipFree(m->d_enc_scratch);
     hipFree(m->d_eps);
     m->stash.release();
@@ -238,7 +236,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     const bool train = flags & CFNERF_F_TRAIN;
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     FwdArgs a{};
-    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
+    a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.rays = rays; a.t_vals = t_vals; a.t_rand = z_vals_opt ? nullptr : t_rand; a.z_in = z_vals_opt; a.eps = eps;
     a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
@@ -282,7 +280,7 @@ int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, 
     if ((gt_opt == nullptr) != (sqerr_opt == nullptr)) return fail(CFNERF_E_INVALID, "gt_opt and sqerr_opt must be given together");
     if (flags & (CFNERF_F_TRAIN | CFNERF_F_STASH)) return fail(CFNERF_E_INVALID, "cfnerf_render_eval is the eval branch only");
     FwdArgs a{};
-    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
+    a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.rays = rays; a.t_vals = t_vals; a.eps = eps;
     a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
     a.kstats = kstats; a.gt = gt_opt; a.sqerr = sqerr_opt; a.enc_scratch = m->d_enc_scratch;
@@ -315,7 +313,7 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     hipStream_t st = (hipStream_t)s;
     FwdArgs a{};
-    a.tab = m->d_tab; a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
+    a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
     int grid = 0;

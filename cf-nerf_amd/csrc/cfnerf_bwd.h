@@ -19,7 +19,6 @@ struct TailArgs {
 };
 
 struct BwdArgs {
-    const NetTab* tab;
     const float* wp;
     const void* wp16;                                     // split-bf16 operand copies (bf16x3 mode)
     int64_t P;

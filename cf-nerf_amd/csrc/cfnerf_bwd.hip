@@ -1284,7 +1284,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
     BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
     BwdArgs ba{};
-    ba.tab = m->d_tab; ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
+    ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_parts = ksplit; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;

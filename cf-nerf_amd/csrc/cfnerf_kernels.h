@@ -12,7 +12,6 @@ namespace cfnerf {
 struct RaysC2W { float m[12]; };
 
 struct FwdArgs {
-    const NetTab* tab;        // device copy of the operand table
     const float* wp;          // packed operands
     const void* wp16;         // split-bf16 copies of the operands (bf16x3 mode)
     const float* flat;        // flat parameters (base-Gaussian mean/std live at [0,8))

@@ -243,7 +243,7 @@ class Trainer:
                                       **_ignored):
         """Coarse pass on ``linspace(0,1,N_samples)`` -> ``cfnerf_sample_pdf`` (depths are constants, as nerf-pytorch
         detaches ``z_samples``) -> fine pass on the merged N_samples + N_importance depths, loss and backward.  With
-        ``coarse_loss`` the coarse pass is run a second time WITH a stash and its own loss term is differentiated too
+        ``coarse_loss`` the coarse pass keeps a stash and its own loss term is differentiated too
         (nerf-pytorch adds img2mse(rgb0); here the same KDE-NLL as the fine term), so ``self.grad`` is the gradient of
         loss_fine + loss_coarse.  Returns it; ``self.scalars`` holds the fine pass's [loss, nll, mse, psnr]."""
         net, lib = self.net, L.lib()
@@ -269,19 +269,17 @@ class Trainer:
         target = _f32c(target)
         beta_w, n_tot = C.c_float(self.beta1 / self.world), N * self.world
         d_ent = L.ptr(self.d_ent) if self.beta1 else None
-        # 1. coarse pass (weights only) + resampling
+        # 1. coarse pass -> per-sample weights -> resampled depths.  With a coarse loss term the same launch also stashes its
+        #    activations, so the coarse term costs one backward, not a second forward.
         w0 = torch.empty(N, S, K, device=dev)
-        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), None, L.ptr(eps), N, S, K, base,
-                                      L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth), None, L.ptr(w0), None, None,
-                                      L.ptr(self.entropy), st), "cfnerf_render_fwd")
+        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), None, L.ptr(eps), N, S, K,
+                                      base | (L.F_STASH if coarse_loss else 0), L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
+                                      None, L.ptr(w0), None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
         z_all = torch.empty(N, S + Ni, device=dev)
         L.check(lib.cfnerf_sample_pdf(L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), base, L.ptr(w0), L.ptr(u), N, S, K, Ni, L.ptr(z_all), st),
                 "cfnerf_sample_pdf")
         grad_c = None
-        if coarse_loss:     # 2. coarse loss term: the same pass again, stashed, and its backward
-            L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(tv), L.ptr(t_rand), None, L.ptr(eps), N, S, K, base | L.F_STASH,
-                                          L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth), None, None, None, None,
-                                          L.ptr(self.entropy), st), "cfnerf_render_fwd")
+        if coarse_loss:     # 2. coarse loss term and its backward (before the fine pass replaces the stash)
             L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(target), L.ptr(self.entropy), N, K, beta_w, n_tot, L.ptr(self.d_rgb),
                                             L.ptr(self.scalars), st), "cfnerf_loss_fwd_bwd")
             grad_c = torch.empty_like(self.grad)
