@@ -6,8 +6,9 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int SHAPE>   // 0: 32x32x2, 1: 16x16x4
+template <int SHAPE>   // 0: 32x32x2 f32, 1: 16x16x4 f32, 2: 32x32x16 bf16 (the split-bf16 mode's instruction)
 __global__ __launch_bounds__(512) void k(float* out, long long* clk, int mode, int n_mfma, int n_valu) {
     const int wave = threadIdx.x >> 6;
     const long long t0 = wall_clock64();
@@ -22,6 +23,17 @@ __global__ __launch_bounds__(512) void k(float* out, long long* clk, int mode, i
                     a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
                     a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+                }
+                r = a0[0] + a1[1] + a2[2] + a3[3];
+            } else if (SHAPE == 2) {
+                f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+                bf16x8 x, y;
+                for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(threadIdx.x * 1e-3f + e); y[e] = (__bf16)(1.0f + 0.01f * e); }
+                for (int i = 0; i < n_mfma; ++i) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+                    a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
                 }
                 r = a0[0] + a1[1] + a2[2] + a3[3];
             } else {
@@ -91,5 +103,6 @@ int main() {
     hipMalloc(&out, (size_t)256 * 512 * 4 * 9); hipMalloc(&clk, 256 * 8 * 8);
     run<0>("32x32x2", out, clk);
     run<1>("16x16x4", out, clk);
+    run<2>("32x32x16bf", out, clk);
     return 0;
 }
