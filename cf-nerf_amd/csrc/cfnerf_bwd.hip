@@ -682,73 +682,84 @@ void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__
     else                                        dw_big_body<PREC, 0>(tiles, blocks, partials, n_params);
 }
 
-// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  Same scheme as 4a at a finer grain:
-//      the 8 waves of a workgroup each own ONE 32 x 32 (or 32 x 64) output tile and are arranged GN x GK over the
-//      job (8 x 1 for a 256 x 63 encoding block, 1 x 8 for a 32 x 256 head, 2 x 4 for 64 x 128 ...), so only tiles
-//      that hold real rows / columns run MFMAs; operands are staged through double-buffered LDS (32 points per
-//      stage, full-row coalesced loads, every dY / X element read from HBM once per tile) with register prefetch.
+// ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  The 8 waves of a workgroup each own ONE
+//      32 x 32 output tile and are arranged GN x GK over the job (4 x 2 for a 128 x 63 encoding block, 2 x 4 for a
+//      32 x 128 head slice ...), so only tiles that hold real rows / columns run MFMAs.  Operands go HBM -> LDS by
+//      LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass, no vector address arithmetic in
+//      the loop) into a THREE-stage ring of 32-point stages, two stages in flight: with one stage in flight the
+//      kernel sat at a 3.2 us stage period against 1.9 us of MFMA work - every stage paid an HBM round trip.
+//      hipcc does not count asm memory operations, so the waits are explicit (s_waitcnt vmcnt(n) with n = the wave's
+//      loads of ONE stage) and the ring is drained before the workgroup ends.
+//      LDS image of a stage: [32 rows][a_ld] dY | [32 rows][b_ld] X, both unpadded and row-major, which is exactly the
+//      lane-linear order LDS-DMA writes (64 lanes x 16 B = 1 KB per instruction); out-of-range rows (ragged last stage,
+//      stages past the block) and columns past the readable row fall outside the descriptor and arrive as zeros.
 constexpr int kDsThreads = 512;
-constexpr int kDsSlots = 5;                   // 16-B loader chunks per thread and stage (32 rows x <= 320 columns)
-constexpr int kDsMaxCols = 288;               // staged columns per row: 32 * GN (dY) + 32 * GK * WK (X); 2 x 72 KB per CU
+constexpr int kDsMaxCols = 192;               // staged columns per row: a_ld (dY) + b_ld (X)
+constexpr int kDsStages = 3;
+constexpr int kDsSlots = 3;                   // LDS-DMA instructions per wave and stage: 8 * 192 chunks / 64 lanes / 8 waves
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 ds_rsrc(const float* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// one 1-KB LDS-DMA piece: lane l's 16 bytes at (descriptor base + soff + voff) land at lds_addr + 16 l.  M0 is written in the
+// statement that reads it and restored (it is compiler-reserved).
+__device__ __forceinline__ void ds_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void ds_wait_stage(int n_w) {   // at most n_w of this wave's pieces still in flight (wave-uniform n_w)
+    if (n_w == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n_w == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+}
+
 __global__ __launch_bounds__(kDsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params,
-                     const float* __restrict__ zeros) {
+void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
-    const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
-    const int GK = t.gk, WK = t.wk, GN = 8 / GK;
-    const int a_ld = 32 * GN, b_ld = 32 * GK * WK;            // floats per staged row
-    float* As = smem;                                         // [2][32][a_ld]
-    float* Bs = smem + 2 * kDwRows * a_ld;                    // [2][32][b_ld]
-    const int64_t pb = blk.pb, pe = blk.pe;
-    gcf_ptr zp = (gcf_ptr)zeros;
-    // loader: a slot is one 16-B chunk per thread.  The first na slots carry dY rows, the next nb slots X rows
-    // (na + nb <= 5); within an operand a slot covers 512 / (chunks per row) consecutive rows, so the per-thread state
-    // is one (row, column) pair per operand and everything that differs between slots is workgroup-uniform.
-    const int ca = a_ld >> 2, cb = b_ld >> 2;                 // chunks per row: 8, 16, 32 or 64
-    const int lca = __builtin_ctz(ca), lcb = __builtin_ctz(cb);
-    const int rpa = kDsThreads >> lca, rpb = kDsThreads >> lcb;           // rows per slot
-    const int na = (kDwRows + rpa - 1) / rpa, nb = (kDwRows + rpb - 1) / rpb;
-    const int ra0 = tid >> lca, cola = 4 * (tid & (ca - 1));
-    const int rb0 = tid >> lcb, colb = 4 * (tid & (cb - 1));
-    const bool a_ok = t.n0 + cola + 4 <= t.Npad, b_ok = t.k0 + colb + 4 <= t.Kpad;   // the vector stays inside the readable row
-    const int a_off0 = ra0 * t.ldY + t.n0 + cola, b_off0 = rb0 * t.ldX + t.k0 + colb;
-    const int a_dst0 = ra0 * a_ld + cola, b_dst0 = rb0 * b_ld + colb;
-    f32x4 rg[kDsSlots];
-    // per-slot source pointers are kept across stages (advanced by a uniform stride), so a stage costs a compare, an
-    // address select and a 64-bit add per slot; rows or columns that do not exist read the zero page (the select is
-    // on the ADDRESS: nothing consumes a load early).  Everything that differs between slots is workgroup-uniform.
-    gcf_ptr src[kDsSlots];
-    bool sok[kDsSlots];
+    const int lane = lane_id_opaque(), wave = __builtin_amdgcn_readfirstlane(wave_id());
+    const int GK = __builtin_amdgcn_readfirstlane(t.gk), GN = 8 / GK;
+    const int tn = min(32 * GN, 128), tk = 32 * GK;
+    // staged widths: whole 32-column groups that hold real rows / columns of this tile
+    const int a_ld = __builtin_amdgcn_readfirstlane(32 * ((min(tn, t.N - t.n0) + 31) / 32));
+    const int b_ld = __builtin_amdgcn_readfirstlane(32 * ((min(tk, t.K - t.k0) + 31) / 32));
+    const int stage_floats = kDwRows * (a_ld + b_ld);
+    const int rows_u = __builtin_amdgcn_readfirstlane((int)(blk.pe - blk.pb));     // a split's point range is far below 2^31 bytes / row
+    const int ldY = __builtin_amdgcn_readfirstlane(t.ldY), ldX = __builtin_amdgcn_readfirstlane(t.ldX);
+    const i32x4 ra = ds_rsrc(t.dY + blk.pb * t.ldY, rows_u * ldY * 4);
+    const i32x4 rb = ds_rsrc(t.X + blk.pb * t.ldX, rows_u * ldX * 4);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    // loader: piece j = wave, wave + 8, wave + 16 of the stage's nI = (a_ld + b_ld) / 8 pieces; pieces [0, nA) carry dY
+    const int nA = a_ld >> 3, nI = (a_ld + b_ld) >> 3;
+    const int n_w = (nI - wave + 7) >> 3;                     // pieces of this wave per stage: 1..3 (nI >= 8)
+    unsigned voff[kDsSlots], loff[kDsSlots];
+    bool is_a[kDsSlots];
 #pragma unroll
     for (int q = 0; q < kDsSlots; ++q) {
-        const bool is_a = q < na;
-        const int j = is_a ? q : q - na;
-        const int row = (is_a ? ra0 : rb0) + j * (is_a ? rpa : rpb);
-        sok[q] = (is_a ? a_ok : b_ok) && (j < (is_a ? na : nb)) && row < kDwRows;
-        src[q] = (is_a ? (gcf_ptr)t.dY + pb * t.ldY : (gcf_ptr)t.X + pb * t.ldX) + ((is_a ? a_off0 : b_off0) + j * (is_a ? rpa * t.ldY : rpb * t.ldX));
+        const int j = wave + 8 * q;
+        is_a[q] = j < nA;
+        const int c = 64 * (is_a[q] ? j : j - nA) + lane;     // 16-B chunk inside the operand's stage image
+        const int cpr = (is_a[q] ? a_ld : b_ld) >> 2;         // chunks per row: 8, 16, 24 or 32
+        const int row = c / cpr, col = (is_a[q] ? t.n0 : t.k0) + 4 * (c - row * cpr);
+        const bool ok = col + 4 <= (is_a[q] ? t.Npad : t.Kpad);          // the vector stays inside the readable row
+        voff[q] = ok ? (unsigned)((row * (is_a[q] ? t.ldY : t.ldX) + col) * 4) : 0x7ffffff0u;
+        loff[q] = (unsigned)(((is_a[q] ? 0 : kDwRows * a_ld) + 256 * (is_a[q] ? j : j - nA)) * 4);
     }
-    auto gload = [&](int rows_left) {
+    const unsigned sa_step = kDwRows * ldY * 4, sb_step = kDwRows * ldX * 4;
+    auto issue = [&](int stage) {                             // stage index: buffer = stage % 3, rows [32 stage, 32 stage + 32)
+        const unsigned base = lds0 + (unsigned)((stage % kDsStages) * stage_floats * 4);
 #pragma unroll
-        for (int q = 0; q < kDsSlots; ++q) {
-            const bool is_a = q < na;
-            const int row = (is_a ? ra0 : rb0) + (is_a ? q * rpa : (q - na) * rpb);
-            gcf_ptr pa = (sok[q] && row < rows_left) ? src[q] : zp;
-            rg[q] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pa);
-            src[q] += kDwRows * (is_a ? t.ldY : t.ldX);
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < kDsSlots; ++q) {
-            const bool is_a = q < na;
-            const int j = is_a ? q : q - na;
-            const int row = (is_a ? ra0 : rb0) + j * (is_a ? rpa : rpb);
-            const bool ok = (j < (is_a ? na : nb)) && row < kDwRows;
-            float* dst = is_a ? As + buf * kDwRows * a_ld + a_dst0 + j * rpa * a_ld : Bs + buf * kDwRows * b_ld + b_dst0 + j * rpb * b_ld;
-            if (ok) *reinterpret_cast<f32x4*>(dst) = rg[q];
-        }
+        for (int q = 0; q < kDsSlots; ++q)
+            if (q < n_w) ds_dma16(is_a[q] ? ra : rb, base + loff[q], voff[q], (unsigned)stage * (is_a[q] ? sa_step : sb_step));
     };
     f32x16 acc[2];
 #pragma unroll
@@ -756,76 +767,50 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     const int gn = wave / GK, gk = wave - gn * GK;
-    const int n_base = t.n0 + 32 * gn, k_base = t.k0 + 32 * WK * gk;
-    const bool active = n_base < t.N && k_base < t.K;         // wave-uniform
+    const int n_base = t.n0 + 32 * gn, k_base = t.k0 + 32 * gk;
+    const bool active = gn * 32 < a_ld && n_base < t.N && k_base < t.K;      // wave-uniform
     const int i = lane & 31, kk = lane >> 5;
-    const float* a_rd = As + kk * a_ld + 32 * gn + i;
-    const float* b_rd = Bs + kk * b_ld + 32 * WK * gk + WK * i;
-    // one stage = 16 point-pairs: the operands of 8 point-pairs are fetched from LDS into registers as a batch, so the
-    // ds_reads pipeline instead of each MFMA waiting on its own read
-    auto compute = [&](int buf) {
+    const float* a_rd = smem + kk * a_ld + 32 * gn + i;
+    const float* b_rd = smem + kDwRows * a_ld + kk * b_ld + 32 * gk + i;
+    // one stage = 16 point-pairs: the operands are fetched from LDS into registers as a batch, so the ds_reads pipeline
+    // instead of each MFMA waiting on its own read
+    auto compute = [&](int stage) {
         if (!active) return;
-        const float* ar = a_rd + buf * kDwRows * a_ld;
-        const float* br = b_rd + buf * kDwRows * b_ld;
-        if (WK == 2) {
+        const float* ar = a_rd + (stage % kDsStages) * stage_floats;
+        const float* br = b_rd + (stage % kDsStages) * stage_floats;
+        float av[16], bv[16];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float av[8]; f32x2 bv[8];
+        for (int pp = 0; pp < 16; ++pp) { av[pp] = ar[pp * 2 * a_ld]; bv[pp] = br[pp * 2 * b_ld]; }
 #pragma unroll
-                for (int pp = 0; pp < 8; ++pp) {
-                    av[pp] = ar[(h * 8 + pp) * 2 * a_ld];
-                    bv[pp] = *reinterpret_cast<const f32x2*>(br + (h * 8 + pp) * 2 * b_ld);
-                }
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) {
-                    acc[0] = CFN_MFMA(av[pp], bv[pp][0], acc[0]);
-                    acc[1] = CFN_MFMA(av[pp], bv[pp][1], acc[1]);
-                }
-            }
-        } else {
-            float av[16], bv[16];
-#pragma unroll
-            for (int pp = 0; pp < 16; ++pp) { av[pp] = ar[pp * 2 * a_ld]; bv[pp] = br[pp * 2 * b_ld]; }
-#pragma unroll
-            for (int pp = 0; pp < 16; ++pp) acc[pp & 1] = CFN_MFMA(av[pp], bv[pp], acc[pp & 1]);   // two chains, summed at the end
-        }
+        for (int pp = 0; pp < 16; ++pp) acc[pp & 1] = CFN_MFMA(av[pp], bv[pp], acc[pp & 1]);   // two chains, summed at the end
     };
 
-    int rows_left = (int)(pe - pb);                  // a split's point range is far below 2^31
-    gload(rows_left);
-    sstore(0);
-    __syncthreads();
-    int buf = 0;
-    for (; rows_left > 0; rows_left -= kDwRows) {
-        const bool more = rows_left > kDwRows;
-        if (more) gload(rows_left - kDwRows);
-        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
-        compute(buf);
-        __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
-        if (more) sstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    const int n_st = (rows_u + kDwRows - 1) / kDwRows;
+    issue(0);
+    issue(1);                                                 // (past the block's end: every lane out of range, zeros, no traffic)
+    for (int s = 0; s < n_st; ++s) {
+        ds_wait_stage(n_w);                                   // this wave's pieces of stage s have landed (stage s + 1 may be in flight)
+        __syncthreads();                                      // ... everyone's have, and everyone is done reading stage s - 1
+        issue(s + 2);                                         // into the buffer stage s - 1 occupied
+        compute(s);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the ring: LDS-DMA must not land after the workgroup has ended
     if (!active) return;
-    if (WK == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
-    }
+    for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
     gf_ptr out = (gf_ptr)(partials + (size_t)blk.split * n_params);
-    for (int tk = 0; tk < WK; ++tk) {
-        const int k = k_base + WK * (lane & 31) + tk;
+    const int k = k_base + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n_base + frag_row(r, lane);
-            if (n < t.N && k < t.K) {
-                int sg = 0;
-                if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
-                if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
-                if (t.nseg > 3 && n >= t.seg_row[3]) sg = 3;
-                const uint32_t dst = sg == 0 ? t.seg_dst[0] : sg == 1 ? t.seg_dst[1] : sg == 2 ? t.seg_dst[2] : t.seg_dst[3];
-                const int row0 = sg == 0 ? t.seg_row[0] : sg == 1 ? t.seg_row[1] : sg == 2 ? t.seg_row[2] : t.seg_row[3];
-                out[(size_t)dst + (size_t)(n - row0) * t.dst_ld + t.dst_col + k] = tk == 0 ? acc[0][r] : acc[1][r];
-            }
+    for (int r = 0; r < 16; ++r) {
+        const int n = n_base + frag_row(r, lane);
+        if (n < t.N && k < t.K) {
+            int sg = 0;
+            if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
+            if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
+            if (t.nseg > 3 && n >= t.seg_row[3]) sg = 3;
+            const uint32_t dst = sg == 0 ? t.seg_dst[0] : sg == 1 ? t.seg_dst[1] : sg == 2 ? t.seg_dst[2] : t.seg_dst[3];
+            const int row0 = sg == 0 ? t.seg_row[0] : sg == 1 ? t.seg_row[1] : sg == 2 ? t.seg_row[2] : t.seg_row[3];
+            out[(size_t)dst + (size_t)(n - row0) * t.dst_ld + t.dst_col + k] = acc[0][r];
         }
     }
 }
@@ -947,7 +932,7 @@ static hipError_t launch_bwd_data(const BwdArgs& a, const NetTab& ht, int prec, 
 constexpr size_t kDwBigLds = 4 * kDwRows * 256 * sizeof(float);
 // (Asking for MORE dynamic LDS than the kernel uses - 96 KB, to keep two 1 x 8 workgroups off one CU - made that launch
 // produce wrong sums on this stack; the XCD-granular budgets of balance_big_splits make it unnecessary anyway.)
-constexpr size_t kDwSmallLds = 2 * kDwRows * kDsMaxCols * sizeof(float);
+constexpr size_t kDwSmallLds = (size_t)kDsStages * kDwRows * kDsMaxCols * sizeof(float);
 
 // Per-DEVICE set-up of the backward kernels of one width (called from cfnerf_model_create with that device current)
 hipError_t bwd_set_attributes(int W, int ha) {
@@ -1031,14 +1016,11 @@ static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
                     int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
     const bool is_big = N >= 128 && Kvalid >= 128;
     int gk = 0, wk = 0;
-    if (!is_big) {
-        const int kcols = std::min(Kvalid, 256);
-        if (kcols <= 32) { gk = 1; wk = 1; }
-        else if (kcols <= 64) { gk = 2; wk = 1; }
-        else if (kcols <= 128) { gk = 4; wk = 1; }
-        else { gk = 8; wk = 1; }
+    if (!is_big) {          // wave arrangement GN x GK (GN GK = 8) from the job's K; a tile stages at most 128 + 64 or 64 + 128 columns
+        wk = 1;
+        gk = Kvalid <= 32 ? 1 : Kvalid <= 64 ? 2 : 4;
     }
-    const int tn = is_big ? 256 : 32 * (8 / gk), tk = is_big ? 256 : 32 * gk * wk;
+    const int tn = is_big ? 256 : std::min(32 * (8 / gk), 128), tk = is_big ? 256 : 32 * gk;
     for (int n0 = 0; n0 < N; n0 += tn)
         for (int k0 = 0; k0 < Kvalid; k0 += tk) {
             DwTile t{};
@@ -1316,7 +1298,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     BHIP(hipEventRecord(B.ev_early, st));
     if (!Hc.blocks_small.empty()) {
         hipLaunchKernelGGL(dw_small_kernel, dim3((unsigned)Hc.blocks_small.size()), dim3(kDsThreads), kDwSmallLds, st,
-                           q.tiles_small, q.blocks_small, q.partials, n_params, q.zeros);
+                           q.tiles_small, q.blocks_small, q.partials, n_params);
         BHIP(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 0);
