@@ -507,6 +507,31 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// ---- LDS-DMA helpers (used by the fp32 big-tile loader and the small-job kernel)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 ds_rsrc(const float* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// one 1-KB LDS-DMA piece: lane l's 16 bytes at (descriptor base + soff + voff) land at lds_addr + 16 l.  M0 is written in the
+// statement that reads it and restored (it is compiler-reserved).
+__device__ __forceinline__ void ds_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void ds_wait_stage(int n_w) {   // at most n_w of this wave's pieces still in flight (wave-uniform n_w)
+    if (n_w == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n_w == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+}
+
 template <int PREC, int ARR>
 __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
                                                       float* __restrict__ partials_, int64_t n_params_) {
@@ -521,6 +546,10 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
     const DwBlock blk = blocks[blockIdx.x];
     const DwTile t = tiles[blk.tile];
     const int tid = threadIdx.x, lane = lane_id_opaque(), wave = wave_id();
+    // fp32: operands go HBM -> LDS by LDS-DMA (one 1-KB piece = one 256-float row of a stage; wave w moves rows w, w + 8, w + 16,
+    // w + 24 of both operands): no staging registers, no ds_write pass between the MFMA blocks.  The split-bf16 mode converts on
+    // the way into LDS and keeps the register path.
+    constexpr bool DMA = PREC == PREC_F32;
     constexpr bool arr1 = ARR == 1;                   // the wave arrangement picks one of two NON-INLINED bodies (two register
                                                       // allocations: one function holding both loop nests spilt its accumulators)
     const int wn = arr1 ? 0 : wave >> 2, wk = arr1 ? wave : wave & 3;
@@ -541,6 +570,21 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
     }
     const int sa_step = kDwRows * ldY * 4, sb_step = kDwRows * ldX * 4;
     int sa = 0, sb = 0;                               // scalar stage offsets
+    const i32x4 da = ds_rsrc(t.dY + blk.pb * t.ldY, rows_u * ldY * 4), db = ds_rsrc(t.X + blk.pb * t.ldX, rows_u * ldX * 4);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    int dma_stage = 0;                                // stage the NEXT issue fetches (advanced in uniform control flow only)
+    auto issue_q = [&](int buf, int q) {              // two of the wave's 8 pieces of stage `dma_stage` -> buffer `buf`
+        const unsigned row_off = ((unsigned)buf * kDwRows + wave_u + 8 * q) * 256 * 4;
+        const unsigned so_a = (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sa_step);
+        const unsigned so_b = (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sb_step);
+        ds_dma16(da, lds0 + row_off, (unsigned)va[q], so_a);
+        ds_dma16(db, lds0 + 2 * kDwRows * 256 * 4 + row_off, (unsigned)vb[q], so_b);
+    };
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_q(buf, q);
+    };
     f32x4 ra[4], rb[4];
     auto gload = [&]() {
 #pragma unroll
@@ -580,14 +624,19 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
     const float* a_rd = As + kk * 256 + 128 * wn + 4 * i;
     const float* b_rd = Bs + kk * 256 + (arr1 ? 32 * wk + i : 64 * wk + 2 * i);
 
-    gload();
-    sstore(0);
-    __syncthreads();
+    if (DMA) { issue(0); dma_stage = 1; }
+    else { gload(); sstore(0); __syncthreads(); }
     int buf = 0;
     for (int p = 0; p < rows_u; p += kDwRows) {      // uniform trip count: keeps the stage offsets in scalar registers
         const bool more = p + kDwRows < rows_u;
-        if (more) gload();
-        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE the MFMA block
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
+            __syncthreads();                                   // ... everyone's have, and everyone is done reading the other buffer
+            if (more && !active) issue(buf ^ 1);               // (active waves spread their pieces over the MFMA block below)
+        } else {
+            if (more) gload();
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ABOVE the MFMA block
+        }
         if (active) {
             if (PREC == PREC_BF16X3) {
                 // two 16-point chunks per stage; lane (i, kk) gathers points 8*kk .. 8*kk+7 of its columns
@@ -639,8 +688,10 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
             } else {
                 const float* ar = a_rd + buf * kDwRows * 256;
                 const float* br = b_rd + buf * kDwRows * 256;
+                // the next stage's pieces go out two at a time between the first MFMA groups instead of as a burst in front of
+                // them (a burst keeps both waves of a SIMD off the matrix pipe at the same moment)
                 if (!arr1) {
-#pragma unroll 4
+#pragma unroll
                     for (int pp = 0; pp < kDwRows / 2; ++pp) {
                         const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
                         const f32x2 bv = *reinterpret_cast<const f32x2*>(br + pp * 512);
@@ -649,21 +700,27 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
                             acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
                             acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
                         }
+                        if (DMA && more && pp < 8 && (pp & 1) == 0) issue_q(buf ^ 1, pp >> 1);
                     }
                 } else {
-#pragma unroll 4
+#pragma unroll
                     for (int pp = 0; pp < kDwRows / 2; ++pp) {
                         const f32x4 av = *reinterpret_cast<const f32x4*>(ar + pp * 512);
                         const float bv = br[pp * 512];
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn) acc[tn][0] = CFN_MFMA(av[tn], bv, acc[tn][0]);
+                        if (DMA && more && pp < 8 && (pp & 1) == 0) issue_q(buf ^ 1, pp >> 1);
                     }
                 }
+
             }
         }
-        __builtin_amdgcn_sched_barrier(0);           // ... and its consumer below it
-        if (more) sstore(buf ^ 1);
-        __syncthreads();
+        if (!DMA) {
+            __builtin_amdgcn_sched_barrier(0);       // ... and its consumer below it
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+        }
+        ++dma_stage;
         buf ^= 1;
     }
     if (active) {
@@ -697,30 +754,6 @@ constexpr int kDsThreads = 512;
 constexpr int kDsMaxCols = 192;               // staged columns per row: a_ld (dY) + b_ld (X)
 constexpr int kDsStages = 3;
 constexpr int kDsSlots = 3;                   // LDS-DMA instructions per wave and stage: 8 * 192 chunks / 64 lanes / 8 waves
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ i32x4 ds_rsrc(const float* base, int bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000;
-    return r;
-}
-// one 1-KB LDS-DMA piece: lane l's 16 bytes at (descriptor base + soff + voff) land at lds_addr + 16 l.  M0 is written in the
-// statement that reads it and restored (it is compiler-reserved).
-__device__ __forceinline__ void ds_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void ds_wait_stage(int n_w) {   // at most n_w of this wave's pieces still in flight (wave-uniform n_w)
-    if (n_w == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (n_w == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-}
-
 __global__ __launch_bounds__(kDsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
