@@ -77,26 +77,29 @@ __device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NTW], const f32x4 a0,
 
 // k-loop, unrolled by two with ping-pong operand registers: the loads of chunk k+1 are issued
 // before the MFMAs of chunk k, so L2 / LDS latency hides under a full block of MFMAs and no
-// register copies are needed.
+// register copies are needed.  The packed operand is read through ONE buffer descriptor over the packed-weight array: a
+// lane keeps a single byte offset (16 * lane) for every n-tile and k-chunk, what differs is a SCALAR offset (so[j] + 1 KB per
+// chunk) - no 64-bit vector address arithmetic between the MFMAs (it came out of their issue slots: 4 of the loop's 6 VALU).
 template <int NTW, int NV>
-__device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const f32x4* const (&bp)[NTW], const float* a_ptr,
-                                         int lda, int KC) {
+__device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const __amdgpu_buffer_rsrc_t wr, const int voff, const int (&so)[NTW],
+                                         const float* a_ptr, int lda, int KC) {
     f32x4 bA[NTW], bB[NTW], a0A, a1A, a0B, a1B;
+    auto bload = [&](int j, int kc) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, so[j] + kc * 1024, 0)); };
     CFN_SETPRIO(CFN_MMA_PRIO);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) bA[j] = bp[j][0];
+    for (int j = 0; j < NV; ++j) bA[j] = bload(j, 0);
     a0A = *reinterpret_cast<const f32x4*>(a_ptr);
     a1A = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda);
     int kc = 0;
     for (; kc + 1 < KC; kc += 2) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) bB[j] = bp[j][(size_t)(kc + 1) * 64];
+        for (int j = 0; j < NV; ++j) bB[j] = bload(j, kc + 1);
         a0B = *reinterpret_cast<const f32x4*>(a_ptr + (kc + 1) * 8);
         a1B = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda + (kc + 1) * 8);
         mma_block<NTW, NV>(acc, a0A, a1A, bA);
         const int k2 = (kc + 2 < KC) ? kc + 2 : KC - 1;       // clamped: the last prefetch re-reads valid data
 #pragma unroll
-        for (int j = 0; j < NV; ++j) bA[j] = bp[j][(size_t)k2 * 64];
+        for (int j = 0; j < NV; ++j) bA[j] = bload(j, k2);
         a0A = *reinterpret_cast<const f32x4*>(a_ptr + k2 * 8);
         a1A = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda + k2 * 8);
         mma_block<NTW, NV>(acc, a0B, a1B, bB);
@@ -119,18 +122,19 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int
     for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
     if (nvalid == 0) return;
     const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5);
-    const f32x4* bp[NTW];
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7ffffff0, 0x00020000);
+    int so[NTW];                                // byte offset of fragment 0 of the wave's n-tiles: wave-uniform
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         int nt = nt0 + j * nts;
         if (nt >= (int)s.nt) nt = nt0;          // never dereferenced (j >= nvalid)
-        bp[j] = reinterpret_cast<const f32x4*>(wp + s.w_off) + (size_t)nt * KC * 64 + lane;
+        so[j] = __builtin_amdgcn_readfirstlane((int)((s.w_off + (unsigned)nt * KC * 256u) * 4u));
     }
     // Every operand of the supported widths (64 / 128 / 256 / 512, heads of 32 / 64 / 96 columns) gives a wave either all
     // NTW of its n-tiles or none (NT is a multiple of the wave count or smaller than it): ONE loop variant per call site, so the
     // accumulators stay in place (a set of partial variants made the compiler shuffle 32 accumulator registers through
     // v_mov_b64 around every GEMM segment).
-    mma_loop<NTW, NTW>(acc, bp, a_ptr, lda, KC);
+    mma_loop<NTW, NTW>(acc, wr, lane * 16, so, a_ptr, lda, KC);
 }
 
 // ================= opt-in split-bf16 ("bf16x3") operand path =====================================
@@ -268,8 +272,9 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     } else {
         const int KC = s.kc, kcp = KC / nparts, k0 = part * kcp;
         const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5) + k0 * 8;
-        const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(wp + s.w_off) + ((size_t)nt * KC + k0) * 64 + lane};
-        mma_loop<1, 1>(acc, bp, a_ptr, lda, kcp);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7ffffff0, 0x00020000);
+        const int so[1] = {__builtin_amdgcn_readfirstlane((int)((s.w_off + ((unsigned)nt * KC + k0) * 256u) * 4u))};
+        mma_loop<1, 1>(acc, wr, lane * 16, so, a_ptr, lda, kcp);
     }
 }
 
