@@ -180,12 +180,16 @@ __device__ __forceinline__ void split_frag(const u32x4 w0, const u32x4 w1, bf16x
 // A chunk is only 12*NV MFMAs (~400-800 cycles) - less than the L2 latency - so the B fragments (global) run
 // kPre16 chunks ahead in a rotating register ring; the A words (LDS, short latency) one chunk ahead.
 template <int NTW, int NV, int kPre16>
-__device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const bf16x8* const (&bp)[NTW], const float* a_ptr, int lda, int KC) {
+__device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const __amdgpu_buffer_rsrc_t wr, const int voff, const int (&so)[NTW],
+                                           const float* a_ptr, int lda, int KC) {
     bf16x8 rb[kPre16][NTW][2];    // [ring slot][n tile][plane]
     u32x4 ra[2][2][2];            // [buf][row tile][half]
-    auto issue_b = [&](int slot, int kc) {
+    auto issue_b = [&](int slot, int kc) {      // one descriptor, one lane offset, scalar chunk / plane offsets (see mma_loop)
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { rb[slot][j][0] = bp[j][(size_t)kc * 128]; rb[slot][j][1] = bp[j][(size_t)kc * 128 + 64]; }
+        for (int j = 0; j < NV; ++j) {
+            rb[slot][j][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, so[j] + kc * 2048, 0));
+            rb[slot][j][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, so[j] + kc * 2048 + 1024, 0));
+        }
     };
     auto issue_a = [&](int buf, int kc) {
 #pragma unroll
@@ -237,14 +241,15 @@ __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, i
     for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
     if (nvalid == 0) return;
     const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5);
-    const bf16x8* bp[NTW];
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
+    int so[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         int nt = nt0 + j * nts;
         if (nt >= (int)s.nt) nt = nt0;
-        bp[j] = reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + (size_t)nt * KC * 128 + lane;
+        so[j] = __builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + (unsigned)nt * KC * 2048u));
     }
-    mma_loop16<NTW, NTW, PRE>(acc, bp, a_ptr, lda, KC);        // all or none of a wave's n-tiles exist: see mma_seg
+    mma_loop16<NTW, NTW, PRE>(acc, wr, lane * 16, so, a_ptr, lda, KC);        // all or none of a wave's n-tiles exist: see mma_seg
 }
 
 // precision-dispatching wrapper used by the fused kernels
@@ -267,8 +272,9 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     if (PREC == PREC_BF16X3) {
         const int KC = s.kc16, kcp = KC / nparts, k0 = part * kcp;
         const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5) + k0 * 16;
-        const bf16x8* bp[1] = {reinterpret_cast<const bf16x8*>(wp16 + s.w16_off) + ((size_t)nt * KC + k0) * 128 + lane};
-        mma_loop16<1, 1, PRE>(acc, bp, a_ptr, lda, kcp);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
+        const int so[1] = {__builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + ((unsigned)nt * KC + k0) * 2048u))};
+        mma_loop16<1, 1, PRE>(acc, wr, lane * 16, so, a_ptr, lda, kcp);
     } else {
         const int KC = s.kc, kcp = KC / nparts, k0 = part * kcp;
         const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5) + k0 * 8;
