@@ -355,11 +355,12 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 const int F = 4;
                 const bool tanh_col = is_rgb ? (c_local >= 9 * F && c_local < 15 * F) : (c_local < 2 * F);
                 float* lp = act + rbase * LD + colb + cl;
-                float* gp = (TRAIN && A.st_theta != nullptr) ? A.st_theta + (p0 + rbase) * kThetaAll + colb + cl : nullptr;
-                // stash mode picked once (wave-uniform): 0 none, 1 every row (full tile), 2 ragged last tile
-                const int stash_mode = (gp == nullptr) ? 0 : (rows_valid >= kTileM ? 1 : 2);
-                auto theta_out = [&](auto mode) {
-                    constexpr int M = decltype(mode)::value;
+                // stash through a slab descriptor over the tile's valid rows (scalar row offsets, ragged rows dropped by the bounds
+                // check): one code path, no 64-bit address arithmetic per element (quarter-rate on this chip)
+                const bool stash = TRAIN && A.st_theta != nullptr;              // wave-uniform
+                const __amdgpu_buffer_rsrc_t sink = slab_rsrc(stash ? A.st_theta + p0 * kThetaAll : nullptr, stash ? rows_valid : 0, kThetaAll);
+                const int voff = (rbase * kThetaAll + colb + cl) * 4;
+                if (is_theta) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -368,14 +369,8 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                             float v = acc[i][0][r] + bv;
                             if (tanh_col) v = tanhf(v);               // diag_activation, MOD:337-348
                             lp[rr * LD] = v;
-                            if (M == 1) st_stream(gp + rr * kThetaAll, v);
-                            if (M == 2) { if (rr + rbase < rows_valid) st_stream(gp + rr * kThetaAll, v); }
+                            if (TRAIN) slab_store(sink, voff, rr * kThetaAll * 4, v);      // (no stash: zero-size descriptor, every store dropped)
                         }
-                };
-                if (is_theta) {
-                    if (stash_mode == 0) theta_out(std::integral_constant<int, 0>{});
-                    else if (stash_mode == 1) theta_out(std::integral_constant<int, 1>{});
-                    else theta_out(std::integral_constant<int, 2>{});
                 }
                 __syncthreads();
             }
