@@ -338,6 +338,32 @@ def test_full_size_train_step_properties(tag, N, K, ndc):
     model.module.release_workspace()
 
 
+def test_repeated_steps_are_bit_identical_soak():
+    """The weight-gradient kernels stage their operands by LDS-DMA with hand-placed s_waitcnt / barriers (hipcc does not track
+    those loads): a missing wait would show up as a rare wrong sum, not as a crash.  300 forward + backward passes of the
+    same full-size batch (and 300 more with ragged 130-sample rays, where stages run past the end of a block) must all
+    return bit-identical gradients."""
+    for S, N in ((128, 1024), (130, 600)):
+        cfg = O.OracleCfg(netwidth=256, K_samples=4)
+        _, _, _, model, p, _ = build_model(cfg, 9)
+        rng = np.random.default_rng(S)
+        rays, (H, Wd, focal) = fern_rays(rng, N)
+        rays = rays.to(DEV)
+        target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32, device=DEV)
+        t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32, device=DEV)
+        eps = torch.tensor(rng.standard_normal((4, 4)), dtype=torch.float32, device=DEV)
+        tv = None if S == 128 else torch.linspace(0., 1., S, device=DEV)
+        tr = TR.Trainer(model, beta1=0.01)
+        ref = tr.forward_backward(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps, t_vals=tv).clone()
+        assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+        bad = 0
+        for _ in range(300):
+            g = tr.forward_backward(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps, t_vals=tv)
+            bad += int(not torch.equal(g, ref))
+        assert bad == 0, f"S={S}: {bad} of 300 repeated steps differ from the first"
+        model.module.release_workspace()
+
+
 def test_large_batch_past_2G_stash_elements():
     """Maximum-size case: 12 288 rays x 128 samples at W = 256 = 1.57 M points, i.e. 3.2e9 stashed trunk activations
     (> 2^31 elements, 12.9 GB for that array alone; 38 GB workspace) - three times the largest BASELINE train batch.  Every
