@@ -315,14 +315,13 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int n
 // acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials.  The dY slab goes out through a buffer
 // descriptor over the tile's valid rows (scalar row offsets, ragged rows dropped by the bounds check: see slab_store);
 // the mask is applied with one v_bfe_i32 + one v_and per element (relu_bit_apply).
-template <int NTW, int PREC>
-__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
-                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
-                                          int rows_valid) {
+template <int NTW, int PREC, bool RAGGED>
+__device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                               float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                               int rows_valid) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, rows_valid, gld);
-    const bool full = rows_valid >= 64;               // wave-uniform
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = nt0 + j * nts;
@@ -338,7 +337,7 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
             for (int r = 0; r < 16; ++r) {
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = relu_bit_apply(mb, i * 16 + r, acc[i][j][r]);
-                if (!full && rr + rbase >= rows_valid) v = 0.f;        // rows past a ragged tile hold garbage activations
+                if (RAGGED && rr + rbase >= rows_valid) v = 0.f;       // rows past a ragged tile hold garbage activations
                 act_store<PREC>(lp + rr * ld, v);
                 slab_store(sink, voff, rr * gld * 4, v);
                 csum += v;
@@ -346,6 +345,15 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }
+}
+// the ragged-row test costs a compare and a select per element: full tiles (all but a ray's last, when S is not a multiple of
+// 64) take the variant without it (wave-uniform branch)
+template <int NTW, int PREC>
+__device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
+                                          float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
+                                          int rows_valid) {
+    if (rows_valid >= 64) store_bwd_impl<NTW, PREC, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
+    else                  store_bwd_impl<NTW, PREC, true>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
 }
 
 template <int W, int PREC>
