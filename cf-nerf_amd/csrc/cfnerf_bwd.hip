@@ -149,13 +149,26 @@ void tail_bwd_kernel(const TailArgs A) {
         const float dz = (s >= S - 1) ? 1e1f : A.z[p + 1] - zv;
         const float dist = dz * dnorm;
 
+        // this kernel runs ONE wave per SIMD (nothing else covers a load's latency): the inputs of latent k + 1 are fetched
+        // while latent k is processed
+        struct KIn { f32x4 rv; f32x2 at; f32x4 e; float G0, G1, G2, Gd; };
+        auto fetch = [&](int k) {
+            KIn q;
+            q.rv = *reinterpret_cast<const f32x4*>(A.raw + (p * K + k) * 4);
+            q.at = *reinterpret_cast<const f32x2*>(A.at + (p * K + k) * 2);
+            q.e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+            q.G0 = A.d_rgb[ray * 3 * (int64_t)K + 0 * K + k]; q.G1 = A.d_rgb[ray * 3 * (int64_t)K + 1 * K + k];
+            q.G2 = A.d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
+            q.Gd = (A.d_depth != nullptr) ? A.d_depth[ray * (int64_t)K + k] : 0.f;
+            return q;
+        };
+        KIn nx = fetch(k_lo);
         for (int k = k_lo; k < k_hi; ++k) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(A.raw + (p * K + k) * 4);
-            const f32x2 at = *reinterpret_cast<const f32x2*>(A.at + (p * K + k) * 2);
-            const float alpha = at[0], Tt = at[1];
-            const float G0 = A.d_rgb[ray * 3 * (int64_t)K + 0 * K + k], G1 = A.d_rgb[ray * 3 * (int64_t)K + 1 * K + k],
-                        G2 = A.d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
-            const float Gd = (A.d_depth != nullptr) ? A.d_depth[ray * (int64_t)K + k] : 0.f;
+            const KIn cur = nx;
+            if (k + 1 < k_hi) nx = fetch(k + 1);
+            const f32x4 rv = cur.rv;
+            const float alpha = cur.at[0], Tt = cur.at[1];
+            const float G0 = cur.G0, G1 = cur.G1, G2 = cur.G2, Gd = cur.Gd;
             const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
             const float w = alpha * Tt;
             float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
@@ -178,7 +191,7 @@ void tail_bwd_kernel(const TailArgs A) {
             if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
 
             // ---- recompute the flows, keeping each step's input and tanh
-            const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+            const f32x4 e = cur.e;
             float zin[4][3], tt[4][3], ain[4], ta[4];
             float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};
             float a = e[3] * a_std + a_mean;
