@@ -179,7 +179,7 @@ class Workload:
         if self.mode == "train":
             from cfnerf_amd import train as T
             self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist,
-                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "1") != "0")
+                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "0") == "1")
         self.hier = hierarchical
 
     def step(self):
