@@ -504,10 +504,11 @@ def lr_schedule(lrate: float, lrate_decay: int, global_step: int) -> float:
 
 def train_step(p: Dict[str, Tensor], packed_rays: Tensor, target_s: Tensor, cfg: OracleCfg,
                eps_alpha: Tensor, eps_rgb: Tensor, t_rand: Optional[Tensor], beta1: float,
-               lindisp=False, white_bkgd=False):
-    """Forward + loss + backward on the oracle.  Returns (scalars, grads dict)."""
+               lindisp=False, white_bkgd=False, t_vals: Optional[Tensor] = None):
+    """Forward + loss + backward on the oracle.  Returns (scalars, grads dict).  `t_vals`: a sample table other than the
+    reference's hard-coded 128 entries (the HIP path accepts one through `t_vals=`; the loss lines are the reference's)."""
     q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    ret = render_rays(q, packed_rays, cfg, eps_alpha, eps_rgb, True, t_rand, lindisp, white_bkgd)
+    ret = render_rays(q, packed_rays, cfg, eps_alpha, eps_rgb, True, t_rand, lindisp, white_bkgd, t_vals=t_vals)
     L = train_loss(ret["rgb_map"], target_s, ret["loss_entropy"], cfg.K_samples, beta1)
     L["loss"].backward()
     grads = {k: v.grad for k, v in q.items()}

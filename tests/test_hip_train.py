@@ -338,6 +338,33 @@ def test_full_size_train_step_properties(tag, N, K, ndc):
     model.module.release_workspace()
 
 
+@pytest.mark.parametrize("S,W,K,N", [(70, 256, 4, 9), (100, 128, 3, 14), (130, 256, 2, 7), (200, 64, 5, 6), (33, 128, 4, 11), (2, 64, 2, 40)])
+def test_gradients_with_ragged_sample_counts_vs_oracle(S, W, K, N):
+    """Sample tables whose length is not a multiple of the 64-point tile (the reference's own table has 128 entries; `t_vals=`
+    overrides it): a ray's last tile is ragged in the forward, in backward-data (masked rows) and in the weight-gradient loaders
+    (stages that run past the end of a block).  Outputs, loss and every gradient against the CPU oracle."""
+    cfg = O.OracleCfg(netwidth=W, K_samples=K)
+    _, _, _, model, p, _ = build_model(cfg, 40 + S)
+    net = model.module
+    rng = np.random.default_rng(S * 7 + W)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    tv = torch.sort(torch.tensor(rng.uniform(0, 1, S), dtype=torch.float32)).values
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    beta1 = 0.02
+    tr = TR.Trainer(net, beta1=beta1)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV),
+                               t_vals=tv.to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, t_vals=tv)
+    close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map")
+    close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map")
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    check_all_grads(net, grad, grads, f"[S={S} W={W} K={K} N={N}, {n_flips} masks differ]")
+
+
 def test_repeated_steps_are_bit_identical_soak():
     """The weight-gradient kernels stage their operands by LDS-DMA with hand-placed s_waitcnt / barriers (hipcc does not track
     those loads): a missing wait would show up as a rare wrong sum, not as a crash.  300 forward + backward passes of the

@@ -97,14 +97,15 @@ def hip_relu_masks(net, P):
 
 
 def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=False, white_bkgd=False,
-                                   max_flip_frac=2e-4):
+                                   max_flip_frac=2e-4, t_vals=None):
     """(scalars, grads, ret, n_flips): the oracle's train step differentiated on the ReLU masks of the HIP forward that
     was just run on the same inputs, after checking that those masks differ from the oracle's own only by rounding."""
-    P = packed.shape[0] * 128 if t_rand is None else t_rand.numel()
+    S = 128 if t_vals is None else int(t_vals.shape[0])
+    P = packed.shape[0] * S
     acts, masks = hip_relu_masks(net, P)
     rec = {}
     with torch.no_grad(), O.relu_override(record=rec):
-        O.render_rays(p, packed, cfg, ea, er, True, t_rand, lindisp, white_bkgd)
+        O.render_rays(p, packed, cfg, ea, er, True, t_rand, lindisp, white_bkgd, t_vals=t_vals)
     n_flips, n_units = 0, 0
     for k, pre in rec.items():
         own = (pre > 0).float()
@@ -118,7 +119,7 @@ def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 
         n_units += flip.numel()
     assert n_flips <= max(2, max_flip_frac * n_units), f"{n_flips} of {n_units} ReLU masks differ"
     with O.relu_override(masks=masks):
-        scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd)
+        scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
     return scal, grads, ret, n_flips
 
 
