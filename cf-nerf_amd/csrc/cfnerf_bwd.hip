@@ -595,13 +595,12 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
     const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
     int dma_stage = 0;                                // stage the NEXT issue fetches (advanced in uniform control flow only)
-    auto issue_q = [&](int buf, int q) {              // two of the wave's 8 pieces of stage `dma_stage` -> buffer `buf`
+    auto issue_h = [&](int buf, int q, int which) {   // ONE of the wave's 8 pieces of stage `dma_stage` -> buffer `buf` (which: 0 dY, 1 X)
         const unsigned row_off = ((unsigned)buf * kDwRows + wave_u + 8 * q) * 256 * 4;
-        const unsigned so_a = (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sa_step);
-        const unsigned so_b = (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sb_step);
-        ds_dma16(da, lds0 + row_off, (unsigned)va[q], so_a);
-        ds_dma16(db, lds0 + 2 * kDwRows * 256 * 4 + row_off, (unsigned)vb[q], so_b);
+        if (which == 0) ds_dma16(da, lds0 + row_off, (unsigned)va[q], (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sa_step));
+        else ds_dma16(db, lds0 + 2 * kDwRows * 256 * 4 + row_off, (unsigned)vb[q], (unsigned)__builtin_amdgcn_readfirstlane(dma_stage * sb_step));
     };
+    auto issue_q = [&](int buf, int q) { issue_h(buf, q, 0); issue_h(buf, q, 1); };
     auto issue = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) issue_q(buf, q);
@@ -721,7 +720,7 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
                             acc[tn][0] = CFN_MFMA(av[tn], bv[0], acc[tn][0]);
                             acc[tn][1] = CFN_MFMA(av[tn], bv[1], acc[tn][1]);
                         }
-                        if (DMA && more && pp < 8 && (pp & 1) == 0) issue_q(buf ^ 1, pp >> 1);
+                        if (DMA && more && pp < 8) issue_h(buf ^ 1, pp >> 1, pp & 1);            // one piece after each of the first 8 MFMA groups
                     }
                 } else {
 #pragma unroll
@@ -730,7 +729,7 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
                         const float bv = br[pp * 512];
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn) acc[tn][0] = CFN_MFMA(av[tn], bv, acc[tn][0]);
-                        if (DMA && more && pp < 8 && (pp & 1) == 0) issue_q(buf ^ 1, pp >> 1);
+                        if (DMA && more && pp < 8) issue_h(buf ^ 1, pp >> 1, pp & 1);            // one piece after each of the first 8 MFMA groups
                     }
                 }
 
