@@ -340,7 +340,7 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
         const int nt = nt0 + j * nts;
         if (nt >= nt_total) continue;
         const int col = nt * 32 + (lane & 31);
-        float* lp = lds_dst + rbase * ld + col;
+        float* lrow = lds_dst + rbase * ld;
         const int voff = (rbase * gld + col) * 4;
         const uint32_t mb = e.mb[j];
         float csum = 0.f;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = relu_bit_apply(mb, i * 16 + r, acc[i][j][r]);
                 if (RAGGED && rr + rbase >= rows_valid) v = 0.f;       // rows past a ragged tile hold garbage activations
-                act_store<PREC>(lp + rr * ld, v);
+                act_store<PREC>(lrow + rr * ld, ld, col, v);
                 slab_store(sink, voff, rr * gld * 4, v);
                 csum += v;
             }
@@ -406,12 +406,12 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD + q * 4 + c, v[c]);
+            for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD, LD, q * 4 + c, v[c]);
         }
         __syncthreads();
         if (tid < kThetaAll) {                                 // bias gradients of the flow-parameter heads
             float s = 0.f;
-            for (int r = 0; r < kTileM; ++r) s += act_load<PREC>(act + r * LD + tid);
+            for (int r = 0; r < kTileM; ++r) s += act_load<PREC>(act + r * LD, LD, tid);
             dbp[A.db_theta + tid] += s;
         }
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
@@ -425,7 +425,7 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
                 mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
             } else {
                 epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
-                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act + kThetaRgb, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act, LD, kThetaRgb);
             }
             __syncthreads();
             if (is_rgb) store_bwd<1, PREC>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);

@@ -150,40 +150,41 @@ __device__ __forceinline__ unsigned pack_hl(float v) {
     const __bf16 l = (__bf16)(v - (float)h);
     return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
 }
+// LDS activation tiles.  fp32 mode: row-major floats, row stride `ld`.  Split-bf16 mode: the SAME row stride in bytes (4 * ld), a
+// row holding its hi plane (bf16 columns from byte 0) and its lo plane (from byte 2 ld + 8: 16-byte aligned, ld = width + 4, so the
+// two planes fill the 4 ld bytes exactly): the 8 consecutive k a lane
+// feeds to v_mfma_f32_32x32x16_bf16 are then 16 contiguous bytes per plane - one ds_read_b128 each, no de-interleave - and the
+// row stride keeps the conflict-free bank pattern of the fp32 tile.  An element is addressed as (row pointer, ld, column).
 template <int PREC>
-__device__ __forceinline__ void act_store(float* p, float v) {
-    if (PREC == PREC_BF16X3) *reinterpret_cast<unsigned*>(p) = pack_hl(v);
-    else *p = v;
+__device__ __forceinline__ void act_store(float* row, int ld, int col, float v) {
+    if (PREC == PREC_BF16X3) {
+        __bf16* r = reinterpret_cast<__bf16*>(row);
+        const __bf16 h = (__bf16)v;
+        r[col] = h;
+        r[ld + 4 + col] = (__bf16)(v - (float)h);
+    } else {
+        row[col] = v;
+    }
 }
 template <int PREC>
-__device__ __forceinline__ float act_load(const float* p) {
+__device__ __forceinline__ float act_load(const float* row, int ld, int col) {
     if (PREC == PREC_BF16X3) {
-        const unsigned w = *reinterpret_cast<const unsigned*>(p);
-        return __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+        const __bf16* r = reinterpret_cast<const __bf16*>(row);
+        return (float)r[col] + (float)r[ld + 4 + col];
     }
-    return *p;
+    return row[col];
 }
 #define CFN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-// 8 consecutive {hi,lo} words of one row -> the hi and lo bf16x8 fragments (v_perm_b32 de-interleave)
-__device__ __forceinline__ void split_frag(const u32x4 w0, const u32x4 w1, bf16x8& hi, bf16x8& lo) {
-    u32x4 h, l;
-    h[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u); l[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
-    h[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u); l[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
-    h[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u); l[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
-    h[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u); l[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
-}
-
 // acc[i][j] += A * B for one operand in the split-bf16 format.  Per 16-k chunk and tile: three MFMAs.
 // A chunk is only 12*NV MFMAs (~400-800 cycles) - less than the L2 latency - so the B fragments (global) run
-// kPre16 chunks ahead in a rotating register ring; the A words (LDS, short latency) one chunk ahead.
+// kPre16 chunks ahead in a rotating register ring; the A fragments (LDS, short latency) one chunk ahead.
+// a_row: this lane's row of the A tile (row lane & 31 of row-tile 0), a_col: bf16 column of its first k (col0 + 8 * (lane >> 5)).
 template <int NTW, int NV, int kPre16>
 __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const __amdgpu_buffer_rsrc_t wr, const int voff, const int (&so)[NTW],
-                                           const float* a_ptr, int lda, int KC) {
+                                           const float* a_row, int a_col, int lda, int KC) {
     bf16x8 rb[kPre16][NTW][2];    // [ring slot][n tile][plane]
-    u32x4 ra[2][2][2];            // [buf][row tile][half]
+    bf16x8 ra[2][2][2];           // [buf][row tile][plane]
     auto issue_b = [&](int slot, int kc) {      // one descriptor, one lane offset, scalar chunk / plane offsets (see mma_loop)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -194,21 +195,19 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const __amdgpu
     auto issue_a = [&](int buf, int kc) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const u32x4* q = reinterpret_cast<const u32x4*>(a_ptr + i * 32 * lda + kc * 16);
-            ra[buf][i][0] = q[0]; ra[buf][i][1] = q[1];
+            const __bf16* q = reinterpret_cast<const __bf16*>(a_row + i * 32 * lda) + a_col + kc * 16;
+            ra[buf][i][0] = *reinterpret_cast<const bf16x8*>(q);              // hi plane
+            ra[buf][i][1] = *reinterpret_cast<const bf16x8*>(q + lda + 4);    // lo plane (2 lda + 8 bytes further)
         }
     };
     auto compute = [&](int buf, int slot) {
-        bf16x8 ah[2], al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) split_frag(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][j] = CFN_MFMA16(al[i], rb[slot][j][0], acc[i][j]);      // small terms first
-                acc[i][j] = CFN_MFMA16(ah[i], rb[slot][j][1], acc[i][j]);
-                acc[i][j] = CFN_MFMA16(ah[i], rb[slot][j][0], acc[i][j]);
+                acc[i][j] = CFN_MFMA16(ra[buf][i][1], rb[slot][j][0], acc[i][j]);      // small terms first: lo * hi
+                acc[i][j] = CFN_MFMA16(ra[buf][i][0], rb[slot][j][1], acc[i][j]);      // hi * lo
+                acc[i][j] = CFN_MFMA16(ra[buf][i][0], rb[slot][j][0], acc[i][j]);      // hi * hi
             }
     };
     const int last = KC - 1;
@@ -233,14 +232,15 @@ __device__ __forceinline__ void mma_loop16(f32x16 (&acc)[2][NTW], const __amdgpu
 
 template <int NTW, int PRE>
 __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const __bf16* __restrict__ wp16,
-                                          const float* lds_a, int lda) {
+                                          const float* lds_a, int lda, int col0) {
     const int lane = lane_id_opaque();
     const int KC = s.kc16;
     int nvalid = 0;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
     if (nvalid == 0) return;
-    const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5);
+    const float* a_row = lds_a + (lane & 31) * lda;
+    const int a_col = col0 + 8 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
     int so[NTW];
 #pragma unroll
@@ -249,16 +249,17 @@ __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, i
         if (nt >= (int)s.nt) nt = nt0;
         so[j] = __builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + (unsigned)nt * KC * 2048u));
     }
-    mma_loop16<NTW, NTW, PRE>(acc, wr, lane * 16, so, a_ptr, lda, KC);        // all or none of a wave's n-tiles exist: see mma_seg
+    mma_loop16<NTW, NTW, PRE>(acc, wr, lane * 16, so, a_row, a_col, lda, KC);        // all or none of a wave's n-tiles exist: see mma_seg
 }
 
 // precision-dispatching wrapper used by the fused kernels
 // PRE: depth of the B-fragment ring of the bf16 loop (2 when two workgroups share a CU, 3 when a wave is alone on its SIMD)
+// lds_a: the A tile (row 0), lda: its row stride in floats, col0: first column of the operand inside the tile
 template <int NTW, int PREC, int PRE = 2>
 __device__ __forceinline__ void mma_any(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const float* __restrict__ wp,
-                                        const __bf16* __restrict__ wp16, const float* lds_a, int lda) {
-    if (PREC == PREC_BF16X3) mma_seg16<NTW, PRE>(acc, s, nt0, nts, wp16, lds_a, lda);
-    else mma_seg<NTW>(acc, s, nt0, nts, wp, lds_a, lda);
+                                        const __bf16* __restrict__ wp16, const float* lds_a, int lda, int col0 = 0) {
+    if (PREC == PREC_BF16X3) mma_seg16<NTW, PRE>(acc, s, nt0, nts, wp16, lds_a, lda, col0);
+    else mma_seg<NTW>(acc, s, nt0, nts, wp, lds_a + col0, lda);
 }
 
 // streaming (touch-once) global traffic: keep it from evicting the L2-resident packed weights
@@ -271,10 +272,10 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     const int ntc = (int)s.nt, nt = wave % ntc, part = wave / ntc, nparts = n_waves / ntc;
     if (PREC == PREC_BF16X3) {
         const int KC = s.kc16, kcp = KC / nparts, k0 = part * kcp;
-        const float* a_ptr = lds_a + (lane & 31) * lda + 8 * (lane >> 5) + k0 * 16;
+        const float* a_row = lds_a + (lane & 31) * lda;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
         const int so[1] = {__builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + ((unsigned)nt * KC + k0) * 2048u))};
-        mma_loop16<1, 1, PRE>(acc, wr, lane * 16, so, a_ptr, lda, kcp);
+        mma_loop16<1, 1, PRE>(acc, wr, lane * 16, so, a_row, 8 * (lane >> 5) + k0 * 16, lda, kcp);
     } else {
         const int KC = s.kc, kcp = KC / nparts, k0 = part * kcp;
         const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5) + k0 * 8;
@@ -350,7 +351,8 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
         if (nt >= (int)s.nt) continue;
         const int col = nt * 32 + (lane & 31);
         const float bv = BIAS_IN_ACC ? 0.f : bias_pre ? bias_pre[j] : (s.b_off != 0xffffffffu) ? wp[s.b_off + col] : 0.f;
-        float* lp = lds_dst + rbase * ld + col0 + col;
+        float* lrow = lds_dst + rbase * ld;
+        const int lcol = col0 + col;
         const int voff = (rbase * gld + col) * 4;
         uint32_t bits = 0;
 #pragma unroll
@@ -360,7 +362,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
                 float v = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
                 if (ACT == ACT_RELU) v = relu_f(v);
-                act_store<PREC>(lp + rr * ld, v);
+                act_store<PREC>(lrow + rr * ld, ld, lcol, v);
                 if (STASH) slab_store(sink, voff, rr * gld * 4, v);
                 if (WANT_BITS) bits = relu_bit_push(bits, v);
             }

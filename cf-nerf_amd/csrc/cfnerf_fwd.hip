@@ -61,11 +61,11 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
                 const int f = p / 3, d = p - 3 * f;
                 float sv = 0.f, cv = 0.f;
                 if (f < nfreq) sincosf(v[d] * (float)(1 << f), &sv, &cv);
-                act_store<PREC>(dst + 3 + 6 * f + d, sv);
-                act_store<PREC>(dst + 3 + 6 * f + 3 + d, cv);
+                act_store<PREC>(dst, LD, 3 + 6 * f + d, sv);
+                act_store<PREC>(dst, LD, 3 + 6 * f + 3 + d, cv);
             } else if (p == 30) {
-                act_store<PREC>(dst + 0, v[0]); act_store<PREC>(dst + 1, v[1]); act_store<PREC>(dst + 2, v[2]);
-                act_store<PREC>(dst + 63, 0.f);
+                act_store<PREC>(dst, LD, 0, v[0]); act_store<PREC>(dst, LD, 1, v[1]); act_store<PREC>(dst, LD, 2, v[2]);
+                act_store<PREC>(dst, LD, 63, 0.f);
             }
         }
     } else {
@@ -73,7 +73,7 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
             const int row = idx >> 6, c = idx & 63;
             float v = 0.f;
             if (c < ic && row < rows_valid) v = x[(p0 + row) * (int64_t)(ic + icv) + c];
-            act_store<PREC>(act + row * LD + c, v);
+            act_store<PREC>(act + row * LD, LD, c, v);
         }
     }
 }
@@ -213,9 +213,9 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                     const int row = idx >> 4, q = idx & 15;
                     if (row < rows_valid) {
                         f32x4 v;
-                        const float* src = act + row * LD + 4 * q;
+                        const float* src = act + row * LD;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = act_load<PREC>(src + c);
+                        for (int c = 0; c < 4; ++c) v[c] = act_load<PREC>(src, LD, 4 * q + c);
                         if (A.st_enc != nullptr) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + row * 64 + 4 * q));
                         else *reinterpret_cast<f32x4*>(dst + row * 64 + 4 * q) = v;
                     }
@@ -240,9 +240,9 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                             f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;           // rows past a ragged tile: finite filler
                             // nt load: served by L2, never by this CU's L1 (the scratch slot is rewritten every tile)
                             if (row < rows_valid) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(enc_park + row * 64 + 4 * q));
-                            float* dstl = act + row * LD + 4 * q;
+                            float* dstl = act + row * LD;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) act_store<PREC>(dstl + c, v[c]);
+                            for (int c = 0; c < 4; ++c) act_store<PREC>(dstl, LD, 4 * q + c, v[c]);
                         }
                     } else {
                         encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
@@ -289,7 +289,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                         float v = pp[0];
                         for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
                         v += wp[T.ha.b_off + c];
-                        act_store<PREC>(hs + row * HLD + c, v);
+                        act_store<PREC>(hs + row * HLD, HLD, c, v);
                         if (A.st_ha != nullptr && row < rows_valid) st_stream(A.st_ha + (p0 + row) * HA + c, v);
                     }
                 }
@@ -312,7 +312,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                     float v;
                     if (MODE == 0) v = gdir[c];
                     else v = (c < icv && row < rows_valid) ? A.x[(p0 + row) * (int64_t)(ic + icv) + ic + c] : 0.f;
-                    act_store<PREC>(act + row * LD + c, v);
+                    act_store<PREC>(act + row * LD, LD, c, v);
                     if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
@@ -343,7 +343,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 const bool is_rgb = wave < 3;               // waves 0-2: the three rgb n-tiles; wave 3: alpha; others idle
                 const bool is_theta = wave < 4;
                 const float bv = wp[(is_rgb ? T.fr.b_off + wave * 32 : T.fa.b_off) + (lane_id_opaque() & 31)];   // lands under the MFMAs
-                if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act + W / 2, LD);
+                if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act, LD, W / 2);
                 else if (is_theta) mma_any<1, PREC, 2>(acc, T.fa, 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
                 const SubL s = is_rgb ? T.fr : T.fa;
