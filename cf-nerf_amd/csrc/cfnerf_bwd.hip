@@ -347,13 +347,16 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {                          // elements r, r + 1: two consecutive rows of this column
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                float v = relu_bit_apply(mb, i * 16 + r, acc[i][j][r]);
-                if (RAGGED && rr + rbase >= rows_valid) v = 0.f;       // rows past a ragged tile hold garbage activations
-                act_store<PREC>(lrow + rr * ld, ld, col, v);
-                slab_store(sink, voff, rr * gld * 4, v);
-                csum += v;
+                float v0 = relu_bit_apply(mb, i * 16 + r, acc[i][j][r]);
+                float v1 = relu_bit_apply(mb, i * 16 + r + 1, acc[i][j][r + 1]);
+                if (RAGGED && rr + rbase >= rows_valid) v0 = 0.f;      // rows past a ragged tile hold garbage activations
+                if (RAGGED && rr + 1 + rbase >= rows_valid) v1 = 0.f;
+                act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, col, v0, v1);
+                slab_store(sink, voff, rr * gld * 4, v0);
+                slab_store(sink, voff, (rr + 1) * gld * 4, v1);
+                csum += v0; csum += v1;
             }
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics

@@ -166,6 +166,26 @@ __device__ __forceinline__ void act_store(float* row, int ld, int col, float v) 
         row[col] = v;
     }
 }
+// two elements of the same column in two rows: in the split-bf16 mode one v_cvt_pk_bf16_f32 converts both hi parts and one
+// both lo parts (3 vector instructions per element instead of 4), the halves of a pair go out as ds_write_b16 / _d16_hi
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int PREC>
+__device__ __forceinline__ void act_store2(float* row_a, float* row_b, int ld, int col, float va, float vb) {
+    if (PREC == PREC_BF16X3) {
+        f32x2_t v; v[0] = va; v[1] = vb;
+        const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        f32x2_t r; r[0] = va - __uint_as_float(hu << 16); r[1] = vb - __uint_as_float(hu & 0xffff0000u);
+        const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+        __bf16* pa = reinterpret_cast<__bf16*>(row_a);
+        __bf16* pb = reinterpret_cast<__bf16*>(row_b);
+        pa[col] = h[0]; pb[col] = h[1];
+        pa[ld + 4 + col] = l[0]; pb[ld + 4 + col] = l[1];
+    } else {
+        row_a[col] = va; row_b[col] = vb;
+    }
+}
 template <int PREC>
 __device__ __forceinline__ float act_load(const float* row, int ld, int col) {
     if (PREC == PREC_BF16X3) {
@@ -358,13 +378,14 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {                         // elements r, r + 1: two consecutive rows of this column
                 const int rr = i * 32 + (r & 3) + 8 * (r >> 2);       // row = rr + rbase
-                float v = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
-                if (ACT == ACT_RELU) v = relu_f(v);
-                act_store<PREC>(lrow + rr * ld, ld, lcol, v);
-                if (STASH) slab_store(sink, voff, rr * gld * 4, v);
-                if (WANT_BITS) bits = relu_bit_push(bits, v);
+                float v0 = BIAS_IN_ACC ? acc[i][j][r] : acc[i][j][r] + bv;
+                float v1 = BIAS_IN_ACC ? acc[i][j][r + 1] : acc[i][j][r + 1] + bv;
+                if (ACT == ACT_RELU) { v0 = relu_f(v0); v1 = relu_f(v1); }
+                act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, lcol, v0, v1);
+                if (STASH) { slab_store(sink, voff, rr * gld * 4, v0); slab_store(sink, voff, (rr + 1) * gld * 4, v1); }
+                if (WANT_BITS) { bits = relu_bit_push(bits, v0); bits = relu_bit_push(bits, v1); }
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
