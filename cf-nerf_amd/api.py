@@ -409,7 +409,10 @@ class NeRF_Flows(nn.Module):
                 L.lib().cfnerf_model_destroy(h)      # synchronises the device before the lent workspace tensor is freed
             except Exception:
                 pass
-            self._h = None
+            try:
+                object.__setattr__(self, "_h", None)     # (nn.Module.__setattr__ may already be torn down at interpreter exit)
+            except Exception:
+                pass
 
 
 class _DataParallelShim(nn.Module):
