@@ -160,7 +160,9 @@ class Workload:
         self.kw_train, self.kw_test = kw_train, kw_test
         self.net = kw_train["network_fn"].module
         self.lib = L.lib()
-        self.lib.cfnerf_timing_enable(self.net.handle, 1)
+        # mode 2: HIP events around the fused forward launch only (2 per step).  Timing every stage (10 events) costs ~1 % of the
+        # step, so the per-stage breakdown is taken in a few extra steps AFTER the timed region (stage_ms)
+        self.lib.cfnerf_timing_enable(self.net.handle, 2)
         self.net.set_precision(precision)
         self.cfnerf = cfnerf_amd
         self.g = torch.Generator(device=dev).manual_seed(1234)  # explicit latents: same on every rank (Trainer enforces it otherwise)
@@ -197,9 +199,21 @@ class Workload:
         with torch.no_grad():
             return self.cfnerf.render(H, Wd, focal, rays=self.rays, near=sc["near"], far=sc["far"], **self.kw_test)
 
-    def kernel_ms(self):
+    def fwd_mean_ms(self, n):
+        """mean duration of the last n fused-forward launches (HIP events on the launch stream, recorded inside the timed region)"""
+        return float(self.lib.cfnerf_timing_fwd_mean_ms(self.net.handle, int(n)))
+
+    def kernel_ms(self, sync, extra_steps=3):
+        """per-stage durations of one step: a few extra steps with every stage timed (outside the timed region)"""
+        h = self.net.handle
+        self.lib.cfnerf_timing_enable(h, 1)
+        for _ in range(extra_steps):
+            self.step()
+        sync()
         names = (("fwd", 0),) + ((("bwd_tail", 1), ("bwd_data", 2), ("bwd_dw", 3), ("adam", 4)) if self.mode == "train" else ())
-        return {k: self.lib.cfnerf_timing_last_ms(self.net.handle, i) for k, i in names}
+        out = {k: self.lib.cfnerf_timing_last_ms(h, i) for k, i in names}
+        self.lib.cfnerf_timing_enable(h, 2)
+        return out
 
     def describe(self, precision):
         c = self.cfg
@@ -278,16 +292,16 @@ def main():
         return float(t.item())
 
     dt = max_over_ranks(timed(wl, args.steps, args.warmup, sync))
-    # per-launch duration of the dominant kernel from the library's HIP events on the launch stream (last step)
-    kms = wl.kernel_ms()
-    fwd_ms = kms["fwd"]
+    # duration of the dominant kernel: mean over the launches of the timed region, HIP events on the launch stream
+    fwd_ms = wl.fwd_mean_ms(args.steps)
+    kms = wl.kernel_ms(sync)
 
     # the opt-in split-bf16 mode, measured the same way right after (every rank runs it: the all-reduce is inside)
     alt = None
     if args.precision == "fp32" and not args.no_alt and name != "C5":
         wl.net.set_precision("bf16x3")
         dta = max_over_ranks(timed(wl, args.steps, min(3, args.warmup) or 1, sync))
-        alt_fwd_ms = wl.kernel_ms()["fwd"]
+        alt_fwd_ms = wl.fwd_mean_ms(args.steps)
         wl.net.set_precision("fp32")
         alt = {"precision": "bf16x3 (opt-in): fp32 operands carried as hi+lo bf16, product = hi*hi + hi*lo + lo*hi on "
                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward, backward-data and the large weight-gradient GEMMs; "
@@ -309,7 +323,9 @@ def main():
         ws = Workload("W512", "train", rank, world, dev, "fp32", False)
         st_steps = max(5, min(20, args.steps))
         dts = timed(ws, st_steps, 3, sync)
-        sk = ws.kernel_ms()
+        sk_fwd = ws.fwd_mean_ms(st_steps)
+        sk = ws.kernel_ms(sync)
+        sk["fwd"] = sk_fwd                      # the roofline figure: mean over the timed steps
         fl = ws.fwd_flops()
         stress = {"workload": ws.describe("fp32"), "value": ws.n * st_steps / dts, "unit": "rays/s", "ms_per_step": dts / st_steps * 1e3,
                   "kernel_ms": sk, "flops_per_ray_fwd": fl / ws.n,

@@ -48,6 +48,7 @@ _SIGS = {
     "cfnerf_model_workspace_bytes": (C.c_int64, [_P]),
     "cfnerf_timing_enable": (C.c_int, [_P, C.c_int]),
     "cfnerf_timing_last_ms": (C.c_float, [_P, C.c_int]),
+    "cfnerf_timing_fwd_mean_ms": (C.c_float, [_P, C.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

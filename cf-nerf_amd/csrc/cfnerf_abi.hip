@@ -51,6 +51,10 @@ static int model_init_device(cfnerf_model* m) {
     HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
     HIPCHK(hipMalloc(&m->d_enc_scratch, (size_t)m->ent_cap * kTileM * 64 * sizeof(float)));
     HIPCHK(hipMalloc(&m->d_eps, kMaxK * 4 * sizeof(float)));
+    for (int i = 0; i < kFwdRing; ++i) {
+        HIPCHK(hipEventCreate(&m->fr0[i]));
+        HIPCHK(hipEventCreate(&m->fr1[i]));
+    }
     for (int i = 0; i < kNumTimers; ++i) {
         HIPCHK(hipEventCreate(&m->ev0[i]));
         HIPCHK(hipEventCreate(&m->ev1[i]));
@@ -165,6 +169,7 @@ int cfnerf_model_destroy(cfnerf_model* m) {
     m->stash.release();
     m->bwd.release();
     for (int i = 0; i < kNumTimers; ++i) { if (m->ev0[i]) hipEventDestroy(m->ev0[i]); if (m->ev1[i]) hipEventDestroy(m->ev1[i]); }
+    for (int i = 0; i < kFwdRing; ++i) { if (m->fr0[i]) hipEventDestroy(m->fr0[i]); if (m->fr1[i]) hipEventDestroy(m->fr1[i]); }
     delete m;
     return CFNERF_OK;
 }
@@ -260,9 +265,9 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         ++q.generation;                      // this forward now owns the one stash: older backward passes are refused
     }
     int grid = 0;
-    if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
+    if (m->timing) HIPCHK(hipEventRecord(m->fr0[m->fwd_launches % kFwdRing], st));
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
-    if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
+    if (m->timing) { HIPCHK(hipEventRecord(m->fr1[m->fwd_launches % kFwdRing], st)); ++m->fwd_launches; }
     if ((flags & CFNERF_F_STASH) && raw_opt)
         HIPCHK(hipMemcpyAsync(raw_opt, m->stash.raw, (size_t)a.P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train)
@@ -286,9 +291,9 @@ int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, 
     a.kstats = kstats; a.gt = gt_opt; a.sqerr = sqerr_opt; a.enc_scratch = m->d_enc_scratch;
     int grid = 0;
     hipStream_t st = (hipStream_t)s;
-    if (m->timing) HIPCHK(hipEventRecord(m->ev0[0], st));
+    if (m->timing) HIPCHK(hipEventRecord(m->fr0[m->fwd_launches % kFwdRing], st));
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, false, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
-    if (m->timing) HIPCHK(hipEventRecord(m->ev1[0], st));
+    if (m->timing) { HIPCHK(hipEventRecord(m->fr1[m->fwd_launches % kFwdRing], st)); ++m->fwd_launches; }
     return CFNERF_OK;
 }
 
@@ -370,14 +375,33 @@ int cfnerf_model_set_workspace(cfnerf_model* m, void* workspace, size_t bytes) {
 
 uint64_t cfnerf_model_stash_generation(const cfnerf_model* m) { return (m && m->stash.valid) ? m->stash.generation : 0; }
 
-int cfnerf_timing_enable(cfnerf_model* m, int enable) {
+int cfnerf_timing_enable(cfnerf_model* m, int mode) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
-    m->timing = enable != 0;
+    if (mode < 0 || mode > 2) return fail(CFNERF_E_INVALID, "timing mode must be 0 (off), 1 (every stage) or 2 (fused forward only)");
+    m->timing = mode;
+    m->fwd_launches = 0;
     return CFNERF_OK;
+}
+
+float cfnerf_timing_fwd_mean_ms(cfnerf_model* m, int n) {
+    if (!m || !m->timing || n < 1 || m->fwd_launches == 0) return -1.f;
+    const uint64_t have = m->fwd_launches < (uint64_t)kFwdRing ? m->fwd_launches : (uint64_t)kFwdRing;
+    const uint64_t take = (uint64_t)n < have ? (uint64_t)n : have;
+    double sum = 0;
+    for (uint64_t i = 0; i < take; ++i) {
+        const int slot = (int)((m->fwd_launches - 1 - i) % kFwdRing);
+        float ms = 0.f;
+        if (hipEventSynchronize(m->fr1[slot]) != hipSuccess) return -1.f;
+        if (hipEventElapsedTime(&ms, m->fr0[slot], m->fr1[slot]) != hipSuccess) return -1.f;
+        sum += ms;
+    }
+    return (float)(sum / (double)take);
 }
 
 float cfnerf_timing_last_ms(cfnerf_model* m, int which) {
     if (!m || which < 0 || which >= kNumTimers || !m->timing) return -1.f;
+    if (which == 0) return cfnerf_timing_fwd_mean_ms(m, 1);
+    if (m->timing != 1) return -1.f;
     float ms = -1.f;
     if (hipEventSynchronize(m->ev1[which]) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, m->ev0[which], m->ev1[which]) != hipSuccess) return -1.f;

@@ -1312,12 +1312,12 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     int ksplit = 1;
     while (ksplit < kTailParts && ksplit * 2 <= q.K && N * ksplit * 2 <= (int64_t)m->n_cu * 4) ksplit *= 2;
     ta.ksplit = ksplit;
-    if (m->timing) BHIP(hipEventRecord(m->ev0[1], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev0[1], st));
     hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N * ksplit, m->flat, d_entropy, grad_flat);
     BHIP(hipGetLastError());
-    if (m->timing) BHIP(hipEventRecord(m->ev1[1], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev1[1], st));
 
     // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
     BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
@@ -1327,15 +1327,15 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
-    if (m->timing) BHIP(hipEventRecord(m->ev0[2], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev0[2], st));
     BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, st, &grid_bd));
-    if (m->timing) BHIP(hipEventRecord(m->ev1[2], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev1[2], st));
     hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
                        q.bias_maps, (int)B.bias_maps.size(), grad_flat);
     BHIP(hipGetLastError());
 
     // ---- 3. weight gradients + reductions
-    if (m->timing) BHIP(hipEventRecord(m->ev0[3], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev0[3], st));
     if (!Hc.blocks.empty()) {
         if (m->precision == PREC_BF16X3)
             hipLaunchKernelGGL(dw_big_kernel<PREC_BF16X3>, dim3((unsigned)Hc.blocks.size()), dim3(kDwThreads), kDwBigLds, st,
@@ -1359,7 +1359,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     }
     hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 0);
     BHIP(hipGetLastError());
-    if (m->timing) BHIP(hipEventRecord(m->ev1[3], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev1[3], st));
     return CFNERF_OK;
 }
 
@@ -1388,12 +1388,12 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
     hipStream_t st = (hipStream_t)s;
     const int64_t n = m->layout.total;
     const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
-    if (m->timing) BHIP(hipEventRecord(m->ev0[4], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev0[4], st));
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat_params, grad_flat, exp_avg, exp_avg_sq, n,
                        (float)(lr / bc1), (float)(1.0 / std::sqrt(bc2)), grad_scale);
     BHIP(hipGetLastError());
     int rc = cfnerf_model_set_params(m, flat_params, s);
-    if (m->timing) BHIP(hipEventRecord(m->ev1[4], st));
+    if (m->timing == 1) BHIP(hipEventRecord(m->ev1[4], st));
     return rc;
 }
 

@@ -11,6 +11,7 @@
 namespace cfnerf {
 
 constexpr int kNumTimers = 5;   // 0 fwd, 1 bwd_tail, 2 bwd_data, 3 bwd_dw, 4 adam
+constexpr int kFwdRing = 64;    // event pairs kept for the forward launch (mean over the last n launches)
 constexpr int kDwSlots = 128;   // split-K slots of the weight-gradient partials (upper bound of any split count)
 constexpr int kMaxDwTiles = 256, kMaxDwBlocks = 16384;     // descriptor capacities carved out of the workspace
 constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over up to this many waves (partial g_theta buffers)
@@ -121,8 +122,10 @@ struct cfnerf_model {
     cfnerf::Stash stash;
     cfnerf::BwdPlan bwd;
     int fwd_blocks_per_cu = 1;            // occupancy of the fused forward on THIS device (set at create)
-    bool timing = false;
+    int timing = 0;                // 0 off, 1 every stage, 2 the fused forward only (two events per step instead of ten)
     hipEvent_t ev0[cfnerf::kNumTimers]{}, ev1[cfnerf::kNumTimers]{};
+    hipEvent_t fr0[cfnerf::kFwdRing]{}, fr1[cfnerf::kFwdRing]{};   // ring of forward-launch event pairs
+    uint64_t fwd_launches = 0;     // timed forward launches so far (ring position = count % kFwdRing)
     size_t ws_bytes = 0;
 };
 

@@ -212,9 +212,13 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 /* bytes currently held by the model: packed weights + the bound workspace, whoever owns it (diagnostics) */
 int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
 
-/* seconds^-3 helper for bench.py: average duration (ms) of the last `n` fused-forward launches
- * measured with HIP events on the launch stream; returns <0 if timing was not enabled.           */
-int   cfnerf_timing_enable(cfnerf_model* m, int enable);
+/* Measurement helpers for bench.py: kernel durations from HIP events recorded on the launch stream.
+ *   mode 0: off (default).  mode 1: every stage of a step (ten events per train step: costs ~1 % of it).
+ *   mode 2: the fused forward launch only (two events per step) - what the timed region of bench.py runs with.
+ * cfnerf_timing_fwd_mean_ms: mean duration (ms) of the last min(n, 64) timed fused-forward launches since the mode was set.
+ * cfnerf_timing_last_ms: last launch of a stage (stages 1..4 need mode 1).  Both return < 0 when nothing was timed.        */
+int   cfnerf_timing_enable(cfnerf_model* m, int mode);
+float cfnerf_timing_fwd_mean_ms(cfnerf_model* m, int n);
 float cfnerf_timing_last_ms(cfnerf_model* m, int which /*0=fwd 1=bwd_tail 2=bwd_data 3=bwd_dw 4=adam*/);
 
 #ifdef __cplusplus
