@@ -36,7 +36,7 @@ def test_default_line_has_the_contract_keys_and_is_self_consistent():
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
     # the kernels of one step cannot take longer than the step
-    assert sum(d["kernel_ms"].values()) <= d["ms_per_step"] * 1.02
+    assert sum(d["kernel_ms"].values()) <= d["ms_per_step"] * 1.05     # (stage times come from extra, event-timed steps)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 50 * c["value"]
