@@ -1,0 +1,53 @@
+"""CPU: the measurement artefacts committed under profiles/ for this round are self-consistent - the bench lines parse and carry
+the contract keys, the rocprofv3 kernel-stats average of the dominant kernel agrees with the duration the bench line reports
+(HIP events) within the few per cent by which profiled passes run slower, and roofline.traffic is the PMC figure on file."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+TAG = "r02"
+
+
+def line(name):
+    with open(os.path.join(P, f"{TAG}_bench_{name}.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name,workload", [("default", "C2"), ("c2", "C2"), ("c3", "C3"), ("c4", "C4"), ("w512", "W512"), ("eval", "C2"), ("c5", "C5"), ("c1", "C1")])
+def test_bench_lines_carry_the_contract(name, workload):
+    d = line(name)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, (name, k)
+    assert d["config"]["workload"].startswith(workload) and d["unit"] == "rays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    if name == "default":
+        assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and "alt_precision" in d and "stress_w512" in d
+
+
+@pytest.mark.parametrize("bench,stats,kernel", [("c2", "train", "fused_fwd_kernel<256, 0, true, 0>"), ("eval", "eval", "fused_fwd_kernel<256, 0, false, 0>"),
+                                                ("w512", "w512_train", "fused_fwd_kernel<512, 0, true, 0>")])
+def test_rocprof_average_agrees_with_the_bench_line(bench, stats, kernel):
+    d = line(bench)
+    with open(os.path.join(P, f"{TAG}_{stats}_kernel_stats.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if kernel in r["Name"]]
+    assert len(rows) == 1, [r["Name"] for r in rows]
+    avg_ms = float(rows[0]["AverageNs"]) / 1e6
+    ev_ms = d["roofline"]["launch_ms"]
+    assert 0.97 * ev_ms <= avg_ms <= 1.10 * ev_ms, (avg_ms, ev_ms)      # profiled passes clock a few per cent lower
+
+
+def test_traffic_is_the_pmc_figure_on_file():
+    with open(os.path.join(P, f"{TAG}_traffic.json")) as f:
+        t = json.load(f)
+    d = line("default")
+    # (the bench line reads the traffic file of the PREVIOUS profiling pass: it is rewritten after the bench ran)
+    assert abs(d["roofline"]["traffic"] - t["C2:train"]["hbm_bytes_per_launch"]) <= 0.02 * t["C2:train"]["hbm_bytes_per_launch"]
+    k = t["C2:train"]
+    assert abs(k["hbm_bytes_per_launch"] - (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024) <= 1e-6 * k["hbm_bytes_per_launch"]
+    assert os.path.exists(os.path.join(P, f"{TAG}_pmc_summary.txt"))
