@@ -1296,7 +1296,6 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
         BHIP(up(q.blocks_small, Hs.blocks_small.data(), Hs.blocks_small.size() * sizeof(DwBlock)));
         BHIP(up(q.segs, Hs.segs.data(), Hs.segs.size() * sizeof(RedSeg)));
         BHIP(up(q.bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap)));
-        BHIP(hipMemsetAsync(q.zeros, 0, 256, st));
         BHIP(hipEventRecord(Hs.uploaded, st));
         B.bind_serial = q.bind_serial;
     }

@@ -46,7 +46,8 @@ struct Stash {
     float *g_h = nullptr;       // [D,P,W]  pre-activation gradients of the trunk layers
     float *dbp = nullptr;       // [n_wg, nb] per-workgroup bias-gradient partials
     float *partials = nullptr;  // [kDwSlots, n_params] split-K weight-gradient partials
-    float *zeros = nullptr;     // 256-B zero page for out-of-range operand fetches
+    float *zeros = nullptr;     // 256 B, unused since the weight-gradient loaders read out-of-range rows as zeros through their
+                                // buffer descriptors (kept so the workspace layout / size does not change)
     BiasMap* bias_maps = nullptr;
     DwTile *tiles = nullptr, *tiles_small = nullptr;
     DwBlock *blocks = nullptr, *blocks_small = nullptr;
