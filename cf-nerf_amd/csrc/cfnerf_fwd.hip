@@ -346,8 +346,6 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act, LD, W / 2);
                 else if (is_theta) mma_any<1, PREC, 2>(acc, T.fa, 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
-                const SubL s = is_rgb ? T.fr : T.fa;
-                const int nt = is_rgb ? wave : 0;
                 const int colb = is_rgb ? wave * 32 : kThetaRgb;
                 const int lo = lane_id_opaque();
                 const int cl = lo & 31, rbase = 4 * (lo >> 5);
