@@ -2,11 +2,14 @@
 """bench.py - headline benchmark of the MI355X-native CF-NeRF ray-batch hot path.
 
     python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C1|W512]
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
+    N > 1: one rank per GPU.  Either the driver starts the ranks (python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N ...: WORLD_SIZE is set) or - plain `python bench.py --gpus N` - this process, which has not touched
+    the GPU, starts them itself as a child torch.distributed.run and relays rank 0's JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic rays of a BASELINE.json config:
-  C2  (default at N = 1, the config the metric is quoted on)  N_rand 1024, K 4, W 256, fern-shaped NDC rays - train step
-  C4  (default at N > 1)  N_rand 1024 per GPU (8192 over 8), K 16 - train step, rays sharded, ONE all-reduce per step
+  C2  (default at EVERY N: the config the metric is quoted on)  N_rand 1024 per GPU, K 4, W 256, fern-shaped NDC rays - train
+      step, rays sharded, ONE all-reduce of the flat gradient per step when N > 1
+  C4  N_rand 1024 per GPU (8192 over 8), K 16 - train step (at N > 1 the default run reports it as `config4_k16` next to the line)
   C3  N_rand 4096, K 8, africa-like (no NDC, near 1.2 / far 8) - train step
   C5  800 x 800 full-image eval, K 32, white background, rows tiled across ranks, fused uncertainty maps - eval
   C1  N_rand 256, K 1 - forward only (the reference's K = 1 train loss is NaN)
@@ -90,7 +93,7 @@ def cpu_baseline(mode, cfg, budget_s=30.0):
     """The CPU oracle (op-for-op PyTorch-CPU restatement of the reference, oracle/) timed on this box's
     host cores on a bounded sample of the same workload.  The thread count is swept (all usable
     cores is NOT the fastest for these GEMM sizes) and the best setting is reported with its count."""
-    from oracle import cfnerf_oracle as O      # the ONLY use of oracle/ in this file: the checker timed as the CPU baseline
+    from oracle import cfnerf_oracle as O      # oracle/ is used by the cpu_baseline leg only: timed here as the CPU baseline, and as the checker of psnr_oracle_agreement
     K, W = cfg["K"], cfg["W"]
     n_rays = min(cfg["n"] or 1024, 1024)        # bounded sample: at most 1024 rays of the per-GPU workload
     sc = SCENES[cfg["scene"]]
@@ -225,15 +228,159 @@ class Workload:
         return gemm_flops_per_point(self.W, self.cfg["ha"]) * self.n * S
 
 
-def timed(wl, steps, warmup, sync):
+def timed(wl, steps, warmup, sync, per_step=None):
+    """W untimed steps, then exactly K steps between two (barrier + device sync) points.  `per_step` (a list) receives the
+    K step durations in ms from one HIP event per step on the launch stream (no host sync inside the region)."""
     for _ in range(warmup):
         wl.step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if ev:
+        ev[0].record()
+    for i in range(steps):
         wl.step()
+        if ev:
+            ev[i + 1].record()
     sync()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if ev:
+        per_step.extend(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return dt
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: THIS process has only imported torch (no GPU call), so it may start
+    the N ranks as a child `python -m torch.distributed.run` (the driver's own launch line), relay rank 0's JSON line as
+    the last line of stdout and return the child's exit code."""
+    import socket
+    import subprocess
+    same_gpu = os.environ.get("CFNERF_BENCH_SAME_GPU") == "1"
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if not same_gpu and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (CFNERF_BENCH_SAME_GPU=1 runs the N-rank code path on one GPU over gloo)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = r.stdout.splitlines()
+    js = [i for i, l in enumerate(lines) if l.startswith("{") and '"metric"' in l]
+    for i, l in enumerate(lines):
+        if not js or i != js[-1]:
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or not js:
+        print(f"bench.py: the {n}-rank run failed (exit code {r.returncode}, JSON line {'found' if js else 'missing'})", file=sys.stderr)
+        return r.returncode or 1
+    print(lines[js[-1]], flush=True)
+    return 0
+
+
+def psnr_block(dev, steps, n_rand=1024, K=4):
+    """PSNR half of the headline metric (RUN:1027-1029: mse2psnr(img2mse(mean_K rgb, target))).  No LLFF-fern data exists
+    here, so the scene is the procedural stand-in of tools/procedural_scene.py, trained through the device ray pool +
+    the fused Trainer; held-out PSNR of the K-mean prediction at a few checkpoints."""
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import procedural_scene as PS
+    import cfnerf_amd
+    from cfnerf_amd import train as T
+    poses, images, i_train, i_test = PS.make(dev)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        kw_train, _, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=256, K_samples=K, device=dev, no_ndc=True,
+                                                                             dataset_type="blender"))
+    net = kw_train["network_fn"].module
+    pool = cfnerf_amd.RayPool(images, poses, PS.H, PS.W, PS.FOCAL, i_train, n_rand, generator=torch.Generator(device=dev).manual_seed(1))
+    tr = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01)
+    g = torch.Generator(device=dev).manual_seed(2)
+    marks = sorted({0, min(250, steps), min(1000, steps), steps})
+    curve = {0: PS.held_out_psnr(net, poses, images, i_test, dev)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, steps + 1):
+        rays, target = pool.next_batch()
+        sc = tr.step(PS.H, PS.W, PS.FOCAL, rays, target.contiguous(), t_rand=torch.rand(n_rand, S, device=dev, generator=g),
+                     eps=torch.randn(K, 4, device=dev, generator=g), near=PS.NEAR, far=PS.FAR, ndc=False)
+        if it in marks:
+            curve[it] = PS.held_out_psnr(net, poses, images, i_test, dev)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out = {"scene": PS.LABEL, "what": "held-out PSNR of the K-mean prediction, mse2psnr(img2mse(mean_K rgb_map, target)) as RUN:1027-1029",
+           "views": f"{len(i_train)} train / {len(i_test)} held out, {PS.H}x{PS.W}", "N_rand": n_rand, "K": K, "W": 256, "steps": steps,
+           "held_out_psnr_db_by_step": {str(k): round(v, 3) for k, v in curve.items()}, "value": round(curve[steps], 3), "unit": "dB",
+           "train_batch_psnr_db_last_step": round(float(sc[3]), 3), "wall_s_incl_eval": round(wall, 2),
+           "lrate": 5e-4, "lrate_decay": 250, "beta1": 0.01, "precision": "fp32"}
+    net.release_workspace()
+    return out
+
+
+def psnr_oracle_agreement(dev, steps=25, n_rand=256, K=4, tol_db=0.05):
+    """Pass/fail: the HIP path and the CPU oracle train on the procedural scene from IDENTICAL weights with identical rays,
+    targets, jitter and latents every step; their held-out PSNR must agree at step 0 and after `steps` steps (studied over 300
+    steps in tests/tools/psnr_curve_vs_oracle.py: 1e-5 dB at step 0, 5e-6 at 25, then fp32 chaos separates any two runs).
+    Part of the cpu_baseline leg: the oracle is the checker here, nothing it computes is reported as performance."""
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import procedural_scene as PS
+    import cfnerf_amd
+    from cfnerf_amd import train as T
+    from oracle import cfnerf_oracle as O
+    poses, images, i_train, i_test = PS.make(dev)
+    view = i_test[1]
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        kw_train, kw_test, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=256, K_samples=K, device=dev, no_ndc=True,
+                                                                                   dataset_type="blender"))
+    net = kw_train["network_fn"].module
+    cfg = O.OracleCfg(netwidth=256, K_samples=K)
+    shapes = O.param_shapes(cfg)
+    sd = net.state_dict()
+    p = {k: sd[k].detach().cpu().clone().reshape(shapes[k]) for k in shapes}
+    ev = net.eval_eps().cpu()
+    ea_eval, er_eval = ev[:, 3:4].clone(), ev[:, 0:3].clone()
+
+    def psnr_hip():
+        return PS.held_out_psnr(net, poses, images, [view], dev)
+
+    def psnr_oracle():
+        with torch.no_grad():
+            out = O.render(p, PS.H, PS.W, PS.FOCAL, cfg, ea_eval, er_eval, False, c2w=poses[view], ndc=False, near=PS.NEAR, far=PS.FAR)
+        return float(-10 * torch.log10(torch.mean((out["rgb_map"].mean(-1) - images[view]) ** 2)))
+
+    ro_all, rd_all, tg_all = [], [], []
+    for v in i_train:
+        ro, rd = PS.camera_rays(poses[v], dev)
+        ro_all.append(ro.cpu()); rd_all.append(rd.cpu()); tg_all.append(images[v].reshape(-1, 3))
+    ro_all, rd_all, tg_all = torch.cat(ro_all), torch.cat(rd_all), torch.cat(tg_all)
+    tr = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01)
+    g = torch.Generator().manual_seed(3)
+    state = {}
+    d0 = abs(psnr_hip() - psnr_oracle())
+    t_cpu = 0.0
+    for it in range(1, steps + 1):
+        sel = torch.randint(0, ro_all.shape[0], (n_rand,), generator=g)
+        ro, rd, tg = ro_all[sel], rd_all[sel], tg_all[sel]
+        t_rand = torch.rand(n_rand, S, generator=g)
+        eps = torch.randn(K, 4, generator=g)
+        tr.step(PS.H, PS.W, PS.FOCAL, (ro.to(dev), rd.to(dev)), tg.to(dev).contiguous(), t_rand=t_rand.to(dev), eps=eps.to(dev),
+                near=PS.NEAR, far=PS.FAR, ndc=False)
+        t0 = time.perf_counter()
+        packed = O.pack_rays(PS.H, PS.W, PS.FOCAL, ro, rd, False, PS.NEAR, PS.FAR)
+        _, grads, _ = O.train_step(p, packed, tg, cfg, eps[:, 3:4], eps[:, 0:3], t_rand, 0.01)
+        p = O.adam_step(p, grads, state, it, O.lr_schedule(5e-4, 250, it - 1))
+        t_cpu += time.perf_counter() - t0
+    ph, po = psnr_hip(), psnr_oracle()
+    net.release_workspace()
+    return {"what": f"HIP path vs CPU oracle, same weights / rays / jitter / latents for {steps} steps of N_rand={n_rand} on the procedural scene",
+            "abs_psnr_diff_db_step0": d0, f"abs_psnr_diff_db_step{steps}": abs(ph - po), "hip_psnr_db": ph, "oracle_psnr_db": po,
+            "tolerance_db": tol_db, "agree": bool(d0 <= tol_db and abs(ph - po) <= tol_db), "oracle_cpu_s_per_step": round(t_cpu / steps, 3)}
 
 
 def main():
@@ -241,19 +388,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: C2 on one GPU, C4 (K=16, 1024 rays/GPU) on several")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: C2 (1024 rays per GPU, K=4) at every GPU count")
     ap.add_argument("--mode", choices=["train", "eval"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements reported next to the main line (bf16x3, W512 stress row)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements reported next to the main line (bf16x3, W512 stress row, "
+                                                          "PSNR block, coarse+fine extension, config 4 at N > 1)")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = exact-fp32 MFMA (default, the measured parity path); bf16x3 = opt-in split-bf16 MFMA mode")
+    ap.add_argument("--psnr-steps", type=int, default=2000, help="train steps of the PSNR block (procedural stand-in scene)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher above us: start the ranks ourselves (nothing in this process has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     # CFNERF_BENCH_SAME_GPU=1 (testing the N > 1 code path on a one-GPU box): every rank uses cuda:0 and the ranks talk over gloo
     same_gpu = os.environ.get("CFNERF_BENCH_SAME_GPU") == "1"
     dev_index = 0 if same_gpu else local_rank
@@ -275,7 +428,7 @@ def main():
     from cfnerf_amd import train as T
     if not T.backward_available():
         raise SystemExit("the backward kernels are not built")
-    name = args.config or ("C2" if world == 1 else "C4")
+    name = args.config or "C2"                 # the SAME workload per GPU at every N: the driver's scaling efficiency compares like with like
     wl = Workload(name, args.mode, rank, world, dev, args.precision, force_dist)
     mode = wl.mode
 
@@ -291,10 +444,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    dt = max_over_ranks(timed(wl, args.steps, args.warmup, sync))
+    step_ms = []
+    dt = max_over_ranks(timed(wl, args.steps, args.warmup, sync, step_ms))
     # duration of the dominant kernel: mean over the launches of the timed region, HIP events on the launch stream
     fwd_ms = wl.fwd_mean_ms(args.steps)
     kms = wl.kernel_ms(sync)
+    extras = world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32" and mode == "train"
 
     # the opt-in split-bf16 mode, measured the same way right after (every rank runs it: the all-reduce is inside)
     alt = None
@@ -315,10 +470,24 @@ def main():
                                    "instructions either and the mode carries 2.6x as many of them (hi/lo splits, v_perm de-interleaves) "
                                    "as the fp32 path (profiles/r02_pmc_summary.txt section pmc_b16, DESIGN.md section 3)"}
 
-    # SURVEY 8d "stress row": the authors' own recipe, next to the headline line (one GPU, default run only)
+    # BASELINE config 4 (K = 16, 1024 rays per GPU) next to the line when the job spans several GPUs (default run only)
+    cfg4 = None
+    if world > 1 and not args.no_alt and args.config is None and args.precision == "fp32" and mode == "train":
+        wl.__dict__.pop("trainer", None)
+        wl.net.release_workspace()
+        w4 = Workload("C4", "train", rank, world, dev, "fp32", force_dist)
+        s4 = max(5, min(20, args.steps))
+        dt4 = max_over_ranks(timed(w4, s4, 3, sync))
+        f4 = w4.fwd_mean_ms(s4)
+        cfg4 = {"workload": w4.describe("fp32"), "value": w4.n * world * s4 / dt4, "unit": "rays/s", "ms_per_step": dt4 / s4 * 1e3, "steps": s4,
+                "fwd_launch_ms": f4, "step_frac_of_peak": 3 * w4.fwd_flops() / (dt4 / s4) / 1e12 / FP32_MFMA_PEAK_TF}
+        w4.net.release_workspace()
+        del w4
+
+    # SURVEY 8d "stress row": the authors' own recipe, next to the headline line (one GPU, default train run only)
     stress = None
-    if world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32":
-        del wl.trainer
+    if extras:
+        wl.__dict__.pop("trainer", None)
         wl.net.release_workspace()
         ws = Workload("W512", "train", rank, world, dev, "fp32", False)
         st_steps = max(5, min(20, args.steps))
@@ -338,7 +507,7 @@ def main():
     # the coarse + fine sampling EXTENSION (BASELINE configs 2/3/5 are worded "64 + 128"; the reference has no second pass, so
     # this is NOT the parity path and never the headline): coarse 64 -> sample_pdf -> fine 64 + 128, both loss terms
     hier = None
-    if world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32":
+    if extras:
         wh = Workload("C2", "train", rank, world, dev, "fp32", False)
         sc = wh.sc
 
@@ -361,27 +530,30 @@ def main():
         wh.net.release_workspace()
         del wh
 
+    # PSNR, the second half of the headline metric, on the synthetic stand-in scene (one GPU, default train run only)
+    psnr = psnr_block(dev, args.psnr_steps) if extras and args.psnr_steps > 0 else None
+
     out = None
     if rank == 0:
         rays_per_s = wl.n * world * args.steps / dt
         fl = wl.fwd_flops()                     # forward GEMM FLOPs of one launch of the fused forward kernel
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
         traffic, mfma_busy, src = None, None, None
-        for prof in ("r02_traffic.json", "r01_traffic.json"):
+        for prof in ("r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
-                    tj = json.load(f)[f"{name}:{mode}" if prof.startswith("r02") else mode]
-                if prof.startswith("r01") and name != "C2":
-                    continue
+                    tj = json.load(f)[f"{name}:{mode}"]
                 traffic, mfma_busy, src = tj["hbm_bytes_per_launch"], tj.get("mfma_busy_frac"), prof
                 break
             except Exception:
                 continue
         roof = {"bound": "mfma", "kernel": f"fused_fwd_kernel<{wl.W},rays,{'train' if mode == 'train' else 'eval'}>",
                 "achieved": fl / (fwd_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": traffic,
-                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{src})" if src else None,
+                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 --pmc passes, profiles/{src}; not "
+                                f"re-measured by this run)" if src else None,
                 "mfma_busy_frac_pmc": mfma_busy, "launch_ms": fwd_ms, "flops_per_launch": fl}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        sm = sorted(step_ms)
         out = {
             "metric": "rays/sec (train step)" if mode == "train" else "rays/sec (eval render, fused forward)",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -390,18 +562,31 @@ def main():
             "config": {"workload": wl.describe(args.precision),
                        "parallelism": f"ray-sharded dp{world}" + (", 1 RCCL all-reduce of flat grads/step" if mode == "train" and world > 1 else "")},
             "roofline": roof,
+            # per-step durations of rank 0 from one HIP event per step inside the timed region (value uses the wall clock over all K)
+            "ms_per_step_median": sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2]),
+            "ms_per_step_min": sm[0], "ms_per_step_max": sm[-1],
         }
+        if same_gpu and world > 1:
+            out["config"]["parallelism"] += " [CFNERF_BENCH_SAME_GPU=1: all ranks share cuda:0 and exchange over gloo - a code-path test, not a scaling number]"
         if mode == "train":
             out["kernel_ms"] = kms
             out["step_frac_of_peak"] = 3 * fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF
+        if psnr is not None:
+            out["psnr"] = psnr
         if alt is not None:
             out["alt_precision"] = alt
+        if cfg4 is not None:
+            out["config4_k16"] = cfg4
         if stress is not None:
             out["stress_w512"] = stress
         if hier is not None:
             out["alt_config"] = hier
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode, wl.cfg)
+            if psnr is not None:
+                wl.__dict__.pop("trainer", None)
+                wl.net.release_workspace()
+                psnr["vs_oracle"] = psnr_oracle_agreement(dev)
 
     # the JSON line is the LAST thing on stdout: RCCL prints its version banner through libc's buffered stdout (it would
     # otherwise surface at process exit, after the line), so every rank flushes that before the final barrier

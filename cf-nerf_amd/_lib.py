@@ -28,6 +28,7 @@ _SIGS = {
     "cfnerf_model_set_params": (C.c_int, [_P, _P, _P]),
     "cfnerf_rays_setup": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), _P, _P, C.c_int64, C.c_int64, C.c_int,
                                     C.c_float, C.c_float, _P, _P]),
+    "cfnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int64, _P, _P, _P]),
     "cfnerf_embed": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "cfnerf_sample_points": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "cfnerf_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,

@@ -75,28 +75,47 @@ def get_embedder(multires, i=0):
 
 
 # --------------------------------------------------------------------------------------------
-# ray helpers (HLP:288-297, 360-377): torch versions for API parity; render() itself uses the
-# cfnerf_rays_setup kernel.
+# ray helpers (HLP:288-297, 360-377) as standalone calls: the same kernels render() uses (cfnerf_rays_setup with a pose,
+# cfnerf_ndc_rays).  GPU only, like everything else here.
+def _pose_arg(c2w):
+    """A [3,4] pose as the `const float* c2w_host` argument.  A pose that already lives on the host is passed as it is
+    (no copy when it is contiguous fp32); a device pose is fetched once (the call needs it on the host: it travels in
+    the kernel arguments).  Returns (ctypes pointer, keep-alive tensor)."""
+    t = torch.as_tensor(c2w)
+    if t.is_cuda:
+        t = t.detach().cpu()
+    t = t.detach()[:3, :4].to(torch.float32).contiguous()
+    return C.cast(t.data_ptr(), C.POINTER(C.c_float)), t
+
+
+def _device_of(*ts, default=None):
+    for t in ts:
+        if torch.is_tensor(t) and t.is_cuda:
+            return t.device
+    return torch.device("cuda", torch.cuda.current_device()) if default is None else default
+
+
 def get_rays(H, W, focal, c2w):
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=c2w.device),
-                          torch.linspace(0, H - 1, H, device=c2w.device), indexing="ij")
-    i, j = i.t(), j.t()
-    dirs = torch.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -torch.ones_like(i)], -1)
-    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
-    rays_o = c2w[:3, -1].expand(rays_d.shape)
-    return rays_o, rays_d
+    """HLP:288-297 on the ray set-up kernel: ``rays_o, rays_d [H,W,3]`` on the GPU (of ``c2w`` if it lives on one, else the
+    current device)."""
+    H, W = int(H), int(W)
+    dev = _device_of(c2w)
+    arr, keep = _pose_arg(c2w)
+    packed = torch.empty(H * W, 11, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().cfnerf_rays_setup(H, W, float(focal), arr, None, None, H * W, 0, 0, 0.0, 1.0, L.ptr(packed), L.stream()),
+                "cfnerf_rays_setup")
+    return packed[:, 0:3].reshape(H, W, 3), packed[:, 3:6].reshape(H, W, 3)
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
-    rays_o = rays_o + t[..., None] * rays_d
-    sx, sy = -1. / (W / (2. * focal)), -1. / (H / (2. * focal))
-    o = torch.stack([sx * rays_o[..., 0] / rays_o[..., 2], sy * rays_o[..., 1] / rays_o[..., 2],
-                     1. + 2. * near / rays_o[..., 2]], -1)
-    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2]),
-                     sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2]),
-                     -2. * near / rays_o[..., 2]], -1)
-    return o, d
+    """HLP:360-377 on ``cfnerf_ndc_rays``."""
+    _need_gpu(rays_d, "rays_d")
+    ro, rd = _f32c(rays_o.reshape(-1, 3)), _f32c(rays_d.reshape(-1, 3))
+    o, d = torch.empty_like(ro), torch.empty_like(rd)
+    L.check(L.lib().cfnerf_ndc_rays(int(H), int(W), float(focal), float(near), L.ptr(ro), L.ptr(rd), ro.shape[0], L.ptr(o), L.ptr(d),
+                                    L.stream()), "cfnerf_ndc_rays")
+    return o.reshape(rays_o.shape), d.reshape(rays_d.shape)
 
 
 _T_VALS_CACHE = {}
@@ -340,6 +359,10 @@ class NeRF_Flows(nn.Module):
         if need < 0:
             raise RuntimeError("cfnerf_workspace_bytes: " + lib.cfnerf_last_error().decode())
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None:
+                # growth is rare: wait for every kernel that may still use the old block (whatever stream it ran on) before the
+                # block goes back to torch's caching allocator
+                torch.cuda.synchronize(self.device)
             L.check(lib.cfnerf_model_set_workspace(self._h, None, 0), "cfnerf_model_set_workspace")   # drop the old block first
             self._ws = None
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -694,12 +717,11 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         raise ValueError("use_viewdirs=False is not supported (the reference's model cannot run it, SURVEY R8)")
     lib = L.lib()
     if c2w is not None:
-        c2w_t = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
         dev = kwargs["network_fn"].module.device if hasattr(kwargs.get("network_fn"), "module") else _unwrap(kwargs["network_fn"]).device
         sh = (H, W, 3)
         N = H * W
         packed = torch.empty(N, 11, device=dev)
-        arr = (C.c_float * 12)(*c2w_t.reshape(-1).tolist())
+        arr, _keep = _pose_arg(c2w)              # a host pose goes into the kernel arguments as it is: no device round trip
         if c2w_staticcam is None:
             L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, int(bool(ndc)), float(near), float(far),
                                           L.ptr(packed), L.stream()), "cfnerf_rays_setup")
@@ -707,8 +729,7 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
             L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr, None, None, N, 0, 0, float(near), float(far), L.ptr(packed),
                                           L.stream()), "cfnerf_rays_setup")
             vd = packed[:, 8:11].clone()
-            sc = torch.as_tensor(c2w_staticcam, dtype=torch.float32).cpu()[:3, :4].contiguous()
-            arr2 = (C.c_float * 12)(*sc.reshape(-1).tolist())
+            arr2, _keep2 = _pose_arg(c2w_staticcam)
             L.check(lib.cfnerf_rays_setup(H, W, float(focal), arr2, None, None, N, 0, int(bool(ndc)), float(near), float(far),
                                           L.ptr(packed), L.stream()), "cfnerf_rays_setup")
             packed[:, 8:11] = vd

@@ -200,6 +200,15 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host, const fl
     return CFNERF_OK;
 }
 
+int cfnerf_ndc_rays(int H, int W, float focal, float near_, const float* rays_o, const float* rays_d, int64_t N, float* out_o, float* out_d,
+                    cfnerf_stream s) {
+    if (N < 0 || H < 1 || W < 1) return fail(CFNERF_E_INVALID, "bad N/H/W");
+    if (N == 0) return CFNERF_OK;
+    if (!rays_o || !rays_d || !out_o || !out_d) return fail(CFNERF_E_INVALID, "NULL argument");
+    HIPCHK(launch_ndc_rays(H, W, focal, near_, rays_o, rays_d, N, out_o, out_d, (hipStream_t)s));
+    return CFNERF_OK;
+}
+
 int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s) {
     if (P < 0 || multires < 1 || multires > 16) return fail(CFNERF_E_INVALID, "bad P / multires (1..16)");
     if (P == 0) return CFNERF_OK;

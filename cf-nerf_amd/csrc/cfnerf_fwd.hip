@@ -626,6 +626,29 @@ __global__ void rays_setup_kernel(int H, int Wd, float focal, RaysC2W c2w, int u
     r[6] = nearv; r[7] = farv; r[8] = vd[0]; r[9] = vd[1]; r[10] = vd[2];
 }
 
+// standalone ndc_rays (HLP:360-377) with the caller's near plane: o, d [N,3] -> o', d' [N,3]
+__global__ void ndc_rays_kernel(int H, int Wd, float focal, float nr, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                int64_t N, float* __restrict__ out_o, float* __restrict__ out_d) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[r] = rays_o[n * 3 + r]; d[r] = rays_d[n * 3 + r]; }
+    const float t = -(nr + o[2]) / d[2];                                                                          // HLP:362
+    o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];                                       // HLP:363
+    const float cw = -1.f / ((float)Wd / (2.f * focal)), chh = -1.f / ((float)H / (2.f * focal));
+    out_o[n * 3 + 0] = cw * o[0] / o[2]; out_o[n * 3 + 1] = chh * o[1] / o[2]; out_o[n * 3 + 2] = 1.f + 2.f * nr / o[2];   // HLP:366-368
+    out_d[n * 3 + 0] = cw * (d[0] / d[2] - o[0] / o[2]);                                                          // HLP:370-372
+    out_d[n * 3 + 1] = chh * (d[1] / d[2] - o[1] / o[2]);
+    out_d[n * 3 + 2] = -2.f * nr / o[2];
+}
+
+hipError_t launch_ndc_rays(int H, int Wd, float focal, float nearv, const float* ro, const float* rd, int64_t N, float* out_o, float* out_d,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, H, Wd, focal, nearv, ro, rd, N, out_o, out_d);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // standalone positional encoding (HLP:21-69) and ray sampling (RUN:510-534): the unfused boundary functions
 __global__ void embed_kernel(const float* __restrict__ x, int64_t P, int nch, float* __restrict__ out) {

@@ -46,6 +46,8 @@ hipError_t launch_composite(const float* raw, const float* z, const float* d, in
                             float* rgb, float* disp, float* depth, float* weights, hipStream_t st);
 hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
                              int64_t N, int64_t pixel0, int ndc, float nearv, float farv, float* out, hipStream_t st);
+hipError_t launch_ndc_rays(int H, int Wd, float focal, float nearv, const float* ro, const float* rd, int64_t N, float* out_o, float* out_d,
+                           hipStream_t st);
 hipError_t launch_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* w, const float* u,
                              int64_t N, int S, int K, int Ni, float* z_out, hipStream_t st);
 hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hipStream_t st);

@@ -13,13 +13,14 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from .api import _pose_arg
 
 
 class RayPool:
     def __init__(self, images, poses, H, W, focal, i_train, N_rand, generator=None, shuffle=True):
         """images [V,H,W,3] in [0,1]; poses [V,3,>=4]; i_train: indices of the training views."""
         images = torch.as_tensor(images, dtype=torch.float32)
-        poses = torch.as_tensor(poses, dtype=torch.float32)
+        poses = torch.as_tensor(poses, dtype=torch.float32).cpu()        # the poses travel in kernel arguments: one fetch for all views
         if not images.is_cuda:
             images = images.cuda()
         dev = images.device
@@ -30,8 +31,7 @@ class RayPool:
         chunks = []
         packed = torch.empty(n, 11, device=dev)
         for v in i_train:
-            c2w = poses[int(v), :3, :4].cpu().contiguous()
-            arr = (C.c_float * 12)(*c2w.reshape(-1).tolist())
+            arr, _keep = _pose_arg(poses[int(v)])
             L.check(lib.cfnerf_rays_setup(self.H, self.W, self.focal, arr, None, None, n, 0, 0, 0.0, 1.0, L.ptr(packed), L.stream()),
                     "cfnerf_rays_setup")
             rays = torch.stack([packed[:, 0:3], packed[:, 3:6], images[int(v)].reshape(n, 3)], 1)      # [n, ro+rd+rgb, 3]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .api import _unwrap, render, t_vals_table
+from .api import _pose_arg, _unwrap, render, t_vals_table
 
 
 def render_path_train(render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
@@ -60,8 +60,7 @@ def render_uncertainty(H, W, focal, c2w, network_fn, near=0., far=1., ndc=True, 
     S = t_vals.shape[0]
     lib = L.lib()
     packed = torch.empty(n, 11, device=dev)
-    c2w_t = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
-    arr = (C.c_float * 12)(*c2w_t.reshape(-1).tolist())
+    arr, _keep = _pose_arg(c2w)
     L.check(lib.cfnerf_rays_setup(int(H), int(W), float(focal), arr, None, None, n, r0 * W, int(bool(ndc)), float(near), float(far),
                                   L.ptr(packed), L.stream()), "cfnerf_rays_setup")
     net._sync()

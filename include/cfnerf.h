@@ -100,6 +100,12 @@ int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] r
                       const float* rays_o, const float* rays_d, int64_t N, int64_t pixel0,
                       int ndc, float near_, float far_, float* rays /*[N,11]*/, cfnerf_stream s);
 
+/* replaces: ndc_rays(H, W, focal, near, rays_o, rays_d) as a standalone call, HLP:360-377 (render() itself goes through
+ * cfnerf_rays_setup, which applies it with near = 1 like RUN:149): rays_o, rays_d [N,3] -> out_o, out_d [N,3] in NDC.
+ * (get_rays, HLP:288-297, as a standalone call is cfnerf_rays_setup with c2w_host and ndc = 0: columns 0..5 of its output.)   */
+int cfnerf_ndc_rays(int H, int W, float focal, float near_, const float* rays_o, const float* rays_d, int64_t N,
+                    float* out_o, float* out_d, cfnerf_stream s);
+
 /* replaces: Embedder.embed / get_embedder(multires) as a standalone call, HLP:21-69:
  * x [P,3] -> out [P, 3 + 6*multires] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]        */
 int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s);

@@ -55,3 +55,27 @@ def trainer_rank(rank, world, port, q, spec):
         import traceback
         q.put((rank, "error", traceback.format_exc(), None, None))
         raise
+
+
+def bench_child(argv, out_path, env):
+    """bench.py as __main__ inside a FRESH fork-server child (it has not touched the GPU, so bench.py may both use the GPU and -
+    for `--gpus N` without a launcher - start its own ranks); stdout (fd 1, C stdio included) goes to `out_path`."""
+    import runpy
+    import sys
+    os.environ.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fd = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.dup2(fd, 1)
+    os.close(fd)
+    sys.stdout = os.fdopen(1, "w", buffering=1, closefd=False)
+    sys.argv = [os.path.join(root, "bench.py"), *argv]
+    os.chdir(root)
+    try:
+        runpy.run_path(sys.argv[0], run_name="__main__")
+    except SystemExit as e:
+        sys.stdout.flush()
+        code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+        if code:
+            print(e.code, file=sys.stderr)
+        os._exit(code)
+    sys.stdout.flush()

@@ -1,10 +1,13 @@
 """-m gpu: bench.py keeps the driver's contract - ONE JSON line last on stdout with the agreed keys (metric / value / unit /
 n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the
-`roofline` and `cpu_baseline` objects, and the numbers in it are consistent with each other."""
+`roofline`, `cpu_baseline` and `psnr` objects, the numbers in it are consistent with each other, and `--gpus N` works both
+under a launcher and on its own.
+
+bench.py runs as __main__ inside a fresh child of the fork server tests/conftest.py starts at collection time, never as a
+fork+exec of this (possibly GPU-initialised) pytest process."""
 import json
 import os
-import subprocess
-import sys
+import tempfile
 
 import pytest
 
@@ -12,17 +15,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, cwd=ROOT, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    last = r.stdout.strip().splitlines()[-1]
+def run_bench(*args, env=None, timeout=900):
+    from conftest import FORKSERVER_CTX as ctx
+    assert ctx is not None, "the fork server must have been started at collection time (tests/conftest.py)"
+    import mp_workers
+    with tempfile.NamedTemporaryFile("r", suffix=".out", delete=False) as f:
+        path = f.name
+    try:
+        p = ctx.Process(target=mp_workers.bench_child, args=(list(args), path, dict(env or {})))
+        p.start()
+        p.join(timeout)
+        assert p.exitcode == 0, f"bench.py {' '.join(args)} exited with {p.exitcode}"
+        with open(path) as f:
+            out = f.read()
+    finally:
+        os.unlink(path)
+    last = out.strip().splitlines()[-1]
     return json.loads(last)
 
 
 def test_default_line_has_the_contract_keys_and_is_self_consistent():
     d = run_bench("--steps", "6", "--warmup", "2", "--no-alt")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "ms_per_step_median"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -30,6 +45,8 @@ def test_default_line_has_the_contract_keys_and_is_self_consistent():
     assert d["config"]["workload"].startswith("C2") and "model" not in d["config"]
     # value = rays of the job / time: 1024 rays per step
     assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    assert 0.9 * d["ms_per_step"] <= d["ms_per_step_median"] <= 1.05 * d["ms_per_step"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 157.3) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
@@ -43,7 +60,43 @@ def test_default_line_has_the_contract_keys_and_is_self_consistent():
 
 
 def test_eval_mode_and_other_configs_run():
-    d = run_bench("--mode", "eval", "--steps", "4", "--warmup", "1", "--no-alt", "--no-cpu-baseline")
+    # eval WITHOUT --no-alt: the train-only side measurements (stress row, extension, PSNR) must stay out of an eval line
+    d = run_bench("--mode", "eval", "--steps", "4", "--warmup", "1", "--no-cpu-baseline")
     assert d["config"]["workload"].startswith("C2") and "eval" in d["config"]["workload"] and d["value"] > 0
+    assert "stress_w512" not in d and "alt_config" not in d and "psnr" not in d and "kernel_ms" not in d
     d = run_bench("--config", "C4", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline")
     assert d["config"]["workload"].startswith("C4") and "K=16" in d["config"]["workload"]
+
+
+def test_psnr_block_is_in_the_default_line():
+    """the second half of the headline metric: held-out PSNR on the synthetic stand-in scene, plus the HIP-vs-oracle agreement"""
+    d = run_bench("--steps", "4", "--warmup", "1", "--psnr-steps", "300")
+    p = d["psnr"]
+    assert "synthetic stand-in for LLFF-fern" in p["scene"] and p["unit"] == "dB" and p["steps"] == 300
+    c = p["held_out_psnr_db_by_step"]
+    assert set(c) == {"0", "250", "300"} and c["300"] > c["0"] + 3.0, c          # it trains: 8.6 dB at init, ~18 dB at 250 steps
+    assert p["value"] == c["300"]
+    v = p["vs_oracle"]
+    assert v["agree"] is True and v["abs_psnr_diff_db_step0"] <= 1e-3 and v["abs_psnr_diff_db_step25"] <= v["tolerance_db"]
+    for k in ("alt_precision", "stress_w512", "alt_config", "cpu_baseline"):
+        assert k in d, k
+
+
+@pytest.mark.parametrize("argv,workload", [(("--config", "C4", "--steps", "4", "--warmup", "2"), "C4"),
+                                           (("--config", "C5", "--steps", "1", "--warmup", "1"), "C5")])
+def test_gpus_2_starts_its_own_ranks(argv, workload):
+    """`python bench.py --gpus 2` with no launcher above it: the process starts its two ranks itself (here both on cuda:0,
+    exchanging over gloo), prints ONE line with n_gpus == 2, and the whole job is about as fast as the same config on one rank
+    (two ranks time-share the one GPU, so the aggregate rate cannot exceed it and should not fall far below)."""
+    env = {"CFNERF_BENCH_SAME_GPU": "1"}
+    one = run_bench("--gpus", "1", *argv, "--no-alt", "--no-cpu-baseline")
+    two = run_bench("--gpus", "2", *argv, "--no-alt", "--no-cpu-baseline", env=env)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["workload"].startswith(workload) and "dp2" in two["config"]["parallelism"]
+    assert "SAME_GPU" in two["config"]["parallelism"]
+    if workload == "C4":
+        assert "all-reduce" in two["config"]["parallelism"]
+        # per rank: 1024 rays per step at both N; value = world * 1024 * steps / time
+        assert abs(two["value"] - 2 * 1024 / (two["ms_per_step"] * 1e-3)) <= 1e-6 * two["value"]
+    ratio = two["value"] / one["value"]
+    assert 0.5 <= ratio <= 1.10, (ratio, one["value"], two["value"])

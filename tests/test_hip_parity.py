@@ -178,6 +178,27 @@ def test_render_c2w_vs_reference_golden(golden):
     close(disp, g["disp_map_static"], atol=ATOL_DISP, rtol=1e-3, what="disp_map (staticcam)")
 
 
+def test_get_rays_and_ndc_rays_helpers_vs_reference_golden(golden):
+    """the standalone ray helpers (HLP:288-297, 360-377) are the product's kernels, not torch restatements: GPU tensors out,
+    the reference's values (fixture G6), a near plane other than 1 against the oracle, CPU tensors rejected"""
+    g = golden("g6_render_c2w")
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    for pose in (T(g["c2w"]), T(g["c2w"]).to(DEV)):                # a host pose goes straight into the call, a device pose is fetched
+        ro, rd = cfnerf_amd.get_rays(H, W, focal, pose)
+        assert ro.is_cuda and list(ro.shape) == [H, W, 3]
+        close(ro, g["rays_o"], atol=0, rtol=0, what="rays_o")
+        close(rd, g["rays_d"], atol=1e-6, rtol=1e-6, what="rays_d")
+    no, nd = cfnerf_amd.ndc_rays(H, W, focal, 1., ro, rd)
+    close(no, g["ndc_o"], atol=2e-6, rtol=1e-5, what="ndc_o")
+    close(nd, g["ndc_d"], atol=2e-6, rtol=1e-5, what="ndc_d")
+    no, nd = cfnerf_amd.ndc_rays(H, W, focal, 0.5, ro, rd)
+    eo, ed = O.ndc_rays(H, W, focal, 0.5, ro.cpu(), rd.cpu())
+    close(no, eo, atol=2e-6, rtol=1e-5, what="ndc_o near=0.5")
+    close(nd, ed, atol=2e-6, rtol=1e-5, what="ndc_d near=0.5")
+    with pytest.raises(RuntimeError):
+        cfnerf_amd.ndc_rays(H, W, focal, 1., ro.cpu(), rd.cpu())
+
+
 @pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True)])
 def test_render_vs_oracle(W, K, N, ndc):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)

@@ -12,49 +12,24 @@ from cfnerf_amd import train as TR, evaluate as E
 from oracle import cfnerf_oracle as O            # deterministic weight generator only
 from util_hip import build_model
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import procedural_scene as PS
+
 DEV = "cuda"
-H, W, FOCAL, NEAR, FAR = 60, 80, 90.0, 2.0, 6.0
-
-
-def pose_spherical(theta_deg, phi_deg, radius):
-    th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
-    trans = np.eye(4); trans[2, 3] = radius
-    rot_phi = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]])
-    rot_th = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
-    c2w = rot_th @ rot_phi @ trans
-    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
-    return torch.tensor(c2w[:3, :4], dtype=torch.float32)
+H, W, FOCAL, NEAR, FAR = PS.H, PS.W, PS.FOCAL, PS.NEAR, PS.FAR
+pose_spherical = PS.pose_spherical
 
 
 def scene(rng, n_blobs=6):
-    return dict(c=torch.tensor(rng.uniform(-0.8, 0.8, (n_blobs, 3)), dtype=torch.float64, device=DEV),
-                s=torch.tensor(rng.uniform(0.25, 0.45, n_blobs), dtype=torch.float64, device=DEV),
-                a=torch.tensor(rng.uniform(3.0, 8.0, n_blobs), dtype=torch.float64, device=DEV),
-                col=torch.tensor(rng.uniform(0.1, 1.0, (n_blobs, 3)), dtype=torch.float64, device=DEV))
+    return PS.blobs(rng, DEV, n_blobs)
 
 
-@torch.no_grad()
 def render_truth(sc, c2w, n_quad=512):
-    ro, rd = cfnerf_amd.get_rays(H, W, FOCAL, c2w.to(DEV))
-    ro, rd = ro.reshape(-1, 3).double(), rd.reshape(-1, 3).double()
-    t = torch.linspace(NEAR, FAR, n_quad, dtype=torch.float64, device=DEV)
-    pts = ro[:, None, :] + rd[:, None, :] * t[None, :, None]                        # [R,Q,3]
-    d2 = ((pts[:, :, None, :] - sc["c"][None, None]) ** 2).sum(-1)                  # [R,Q,B]
-    dens = sc["a"] * torch.exp(-d2 / (2 * sc["s"] ** 2))
-    sigma = dens.sum(-1)
-    col = (dens[..., None] * sc["col"]).sum(-2) / (sigma[..., None] + 1e-12)
-    delta = (t[1] - t[0]) * rd.norm(dim=-1, keepdim=True)
-    alpha = 1 - torch.exp(-sigma * delta)
-    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
-    return ((alpha * T)[..., None] * col).sum(1).reshape(H, W, 3).float()
+    return PS.render_truth(sc, c2w, DEV, n_quad)
 
 
 def psnr_of(model, poses, images, idx):
-    ps = []
-    for v in idx:
-        out = E.render_uncertainty(H, W, FOCAL, poses[v], model, near=NEAR, far=FAR, ndc=False)
-        ps.append(float(-10 * torch.log10(torch.mean((out["rgb_mean"] - images[v].to(DEV)) ** 2))))
-    return float(np.mean(ps))
+    return PS.held_out_psnr(model, poses, images, idx, DEV)
 
 
 def main(steps=3000, N_rand=1024, K=4):

@@ -3,6 +3,7 @@
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run this through gpurun}"
 cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
 for i in 1 2; do
 for v in "$@"; do
   if [ "$v" = default ]; then unset CFNERF_LIB; else export CFNERF_LIB=$GRAFT_REPO_ROOT/$v; fi
