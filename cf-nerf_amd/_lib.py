@@ -42,6 +42,8 @@ _SIGS = {
     "cfnerf_model_set_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "cfnerf_model_stash_generation": (C.c_uint64, [_P]),
     "cfnerf_render_bwd": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "cfnerf_network_bwd": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P]),
+    "cfnerf_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "cfnerf_grad_early_ranges": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "cfnerf_stream_wait_grad_early": (C.c_int, [_P, _P]),
     "cfnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),

@@ -405,8 +405,6 @@ class NeRF_Flows(nn.Module):
         _need_gpu(x, "x")
         if x.shape[-1] != self.input_ch + self.input_ch_views:
             raise ValueError(f"x must have {self.input_ch + self.input_ch_views} channels, got {x.shape[-1]}")
-        if torch.is_grad_enabled() and self.flat.requires_grad and not is_test:
-            raise RuntimeError("autograd through NeRF_Flows.forward is not available; train through render()/render_rays()")
         self._sync()
         xf = _f32c(x.reshape(-1, x.shape[-1]))
         P, K = xf.shape[0], self.K_samples
@@ -416,6 +414,11 @@ class NeRF_Flows(nn.Module):
             eps = self._next_eps
         else:
             eps = self.eval_eps() if is_test else self.draw_eps()
+        if torch.is_grad_enabled() and self.flat.requires_grad and not is_test and P > 0:
+            # the reference's forward is an autograd graph (MOD:188-291): so is this one - cfnerf_network_fwd with the
+            # activation stash, differentiated by cfnerf_network_bwd (gradients reach the parameters; x is a constant)
+            raw, ent = _NetworkFn.apply(self.flat, self, xf, eps)
+            return raw, ent.reshape(1, 1, 1).expand(P, K, 1)         # MOD:291
         raw = torch.empty(P, K, 4, device=self.device, dtype=torch.float32)
         ent = torch.zeros(1, device=self.device, dtype=torch.float32)
         flags = 0 if is_test else L.F_TRAIN
@@ -436,6 +439,78 @@ class NeRF_Flows(nn.Module):
                 object.__setattr__(self, "_h", None)     # (nn.Module.__setattr__ may already be torn down at interpreter exit)
             except Exception:
                 pass
+
+
+class _NetworkFn(torch.autograd.Function):
+    """NeRF_Flows.forward as an autograd node: cfnerf_network_fwd with the activation stash + cfnerf_network_bwd.  The model has
+    ONE stash.  If a later grad-enabled forward replaced it before this node's backward runs (several chunks of one batch through
+    a caller's own batchify loop), the node re-runs its forward from the inputs it kept (x, latents - the parameters cannot
+    have changed in between) and then differentiates: chunked callers train, at the price of one extra forward per chunk."""
+
+    @staticmethod
+    def _forward_stash(model, xf, eps, raw, ent):
+        P, K = xf.shape[0], eps.shape[0]
+        model.ensure_workspace(1, P, K)
+        lib = L.lib()
+        L.check(lib.cfnerf_network_fwd(model.handle, L.ptr(xf), L.ptr(eps), P, K, L.F_TRAIN | L.F_STASH, L.ptr(raw), L.ptr(ent), L.stream()),
+                "cfnerf_network_fwd")
+        return lib.cfnerf_model_stash_generation(model.handle)
+
+    @staticmethod
+    def forward(ctx, flat, model, xf, eps):
+        P, K = xf.shape[0], eps.shape[0]
+        raw = torch.empty(P, K, 4, device=xf.device)
+        ent = torch.zeros(1, device=xf.device)
+        ctx.generation = _NetworkFn._forward_stash(model, xf, eps, raw, ent)
+        ctx.model, ctx.xf, ctx.eps, ctx.n_params = model, xf, eps, flat.numel()
+        return raw, ent.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_raw, d_ent):
+        model, lib = ctx.model, L.lib()
+        if lib.cfnerf_model_stash_generation(model.handle) != ctx.generation:
+            P, K = ctx.xf.shape[0], ctx.eps.shape[0]
+            ctx.generation = _NetworkFn._forward_stash(model, ctx.xf, ctx.eps, torch.empty(P, K, 4, device=ctx.xf.device),
+                                                       torch.zeros(1, device=ctx.xf.device))
+        grad = torch.empty(ctx.n_params, device=model.flat.device)
+        dr = _f32c(d_raw) if d_raw is not None else None
+        de = _f32c(d_ent.reshape(1)) if d_ent is not None else None
+        if dr is None and de is None:
+            return torch.zeros(ctx.n_params, device=model.flat.device), None, None, None
+        L.check(lib.cfnerf_network_bwd(model.handle, ctx.generation, L.ptr(dr), L.ptr(de), L.ptr(grad), L.stream()), "cfnerf_network_bwd")
+        return grad, None, None, None
+
+
+class _CompositeFn(torch.autograd.Function):
+    """raw2outputs (RUN:411-454) as an autograd node: cfnerf_composite_fwd + cfnerf_composite_bwd (stateless; differentiable with
+    respect to raw through every output: rgb_map, disp_map, weights, depth_map)."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, white_bkgd):
+        N, S, K = raw.shape[0], raw.shape[1], raw.shape[2]
+        dev = raw.device
+        rgb_map = torch.empty(N, 3, K, device=dev)
+        disp_map = torch.empty(N, K, device=dev)
+        depth_map = torch.empty(N, K, device=dev)
+        weights = torch.empty(N, S, K, device=dev)
+        L.check(L.lib().cfnerf_composite_fwd(L.ptr(raw), L.ptr(z_vals), L.ptr(rays_d), N, S, K, int(bool(white_bkgd)), L.ptr(rgb_map),
+                                             L.ptr(disp_map), L.ptr(depth_map), L.ptr(weights), L.stream()), "cfnerf_composite_fwd")
+        ctx.save_for_backward(raw, z_vals, rays_d)
+        ctx.white_bkgd = int(bool(white_bkgd))
+        return rgb_map, disp_map, weights, depth_map
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_disp, d_weights, d_depth):
+        raw, z_vals, rays_d = ctx.saved_tensors
+        N, S, K = raw.shape[0], raw.shape[1], raw.shape[2]
+        if N == 0 or (d_rgb is None and d_disp is None and d_weights is None and d_depth is None):
+            return torch.zeros_like(raw), None, None, None
+        d_raw = torch.empty_like(raw)
+        g_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(N, 3, K, device=raw.device)
+        c = lambda t: _f32c(t) if t is not None else None
+        L.check(L.lib().cfnerf_composite_bwd(L.ptr(raw), L.ptr(z_vals), L.ptr(rays_d), N, S, K, ctx.white_bkgd, L.ptr(g_rgb), L.ptr(c(d_disp)),
+                                             L.ptr(c(d_depth)), L.ptr(c(d_weights)), L.ptr(d_raw), L.stream()), "cfnerf_composite_bwd")
+        return d_raw, None, None, None
 
 
 class _DataParallelShim(nn.Module):
@@ -465,6 +540,10 @@ def batchify(fn, chunk):
         return fn
 
     def ret(inputs, is_val, is_test):
+        m = getattr(fn, "module", fn)
+        if isinstance(m, NeRF_Flows) and torch.is_grad_enabled() and m.flat.requires_grad and not is_test:
+            # one launch = the model's one stash; chunks would each replace it and the backward would re-run their forwards
+            return fn(inputs, is_val, is_test)
         A, B = [], []
         for i in range(0, inputs.shape[0], chunk):
             a, b = fn(inputs[i:i + chunk], is_val, is_test)
@@ -492,6 +571,9 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     exactly like the reference (the noise is generated but never added, RUN:432-442)."""
     _need_gpu(raw, "raw")
     N, S, K = raw.shape[0], raw.shape[1], raw.shape[2]
+    if torch.is_grad_enabled() and raw.requires_grad:                # differentiable like the reference's (with respect to raw)
+        rc = raw.to(torch.float32).contiguous()
+        return _CompositeFn.apply(rc, _f32c(z_vals), _f32c(rays_d), bool(white_bkgd))
     raw_c, z_c, d_c = _f32c(raw), _f32c(z_vals), _f32c(rays_d)
     dev = raw.device
     rgb_map = torch.empty(N, 3, K, device=dev)

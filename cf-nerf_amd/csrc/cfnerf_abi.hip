@@ -270,7 +270,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         a.raw = q.raw;                       // the backward reads the model's OWN copy: the caller may drop its tensor
         HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true;
+        q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true; q.points = false;
         ++q.generation;                      // this forward now owns the one stash: older backward passes are refused
     }
     int grid = 0;
@@ -319,10 +319,10 @@ int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_ran
 int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags, float* raw,
                        float* entropy_out, cfnerf_stream s) {
     if (int rc = check_common(m, K)) return rc;
-    if (flags & CFNERF_F_STASH) return fail(CFNERF_E_UNSUPPORTED, "STASH is only available through cfnerf_render_fwd");
-    if (P < 0) return fail(CFNERF_E_INVALID, "bad P");
+    if (P < 0 || P > 0x7fffffff) return fail(CFNERF_E_INVALID, "bad P");
     if (P == 0) return CFNERF_OK;
     if (!x || !eps || !raw) return fail(CFNERF_E_INVALID, "NULL argument");
+    if (flags & CFNERF_F_STASH) flags |= CFNERF_F_TRAIN;
     const bool train = flags & CFNERF_F_TRAIN;
     if (train && !entropy_out) return fail(CFNERF_E_INVALID, "TRAIN needs entropy_out");
     hipStream_t st = (hipStream_t)s;
@@ -330,8 +330,24 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
+    if (flags & CFNERF_F_STASH) {            // points-mode stash: the workspace is bound as ONE "ray" of P samples
+        char why[256];
+        if (int rc = stash_bind(m, 1, (int)P, K, why, sizeof why)) return fail(rc, "%s", why);
+        Stash& q = m->stash;
+        a.st_enc = q.enc; a.st_gd = q.gd; a.st_h = q.h; a.st_feat = q.feat; a.st_v = q.v; a.st_ha = q.ha; a.st_hr = q.hr;
+        a.st_theta = q.theta;
+        a.st_mbits = reinterpret_cast<uint32_t*>(q.mbits);
+        q.n_tiles = (P + kTileM - 1) / kTileM;
+        a.n_tiles = q.n_tiles;
+        a.raw = q.raw;                       // the backward reads the model's OWN copy
+        HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        q.N = 1; q.S = (int)P; q.K = K; q.flags = flags; q.valid = true; q.points = true;
+        ++q.generation;
+    }
     int grid = 0;
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
+    if (flags & CFNERF_F_STASH)
+        HIPCHK(hipMemcpyAsync(raw, m->stash.raw, (size_t)P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out, st));
     return CFNERF_OK;

@@ -104,6 +104,112 @@ __device__ __forceinline__ float t_exp(float x) { return __builtin_amdgcn_exp2f(
 __device__ __forceinline__ float t_tanh(float x) { return 1.f - 2.f * t_rcp(1.f + t_exp(2.f * x)); }
 __device__ __forceinline__ float t_sigmoid(float x) { return t_rcp(1.f + t_exp(-x)); }
 
+// Adjoint of the four conditional Sylvester flows (FLW:225-268, MOD:401-413) for ONE (point, latent sample): recomputes the
+// forward keeping each step's input and tanh, then walks it backwards.  In: th = the point's flow parameters, e = the latent,
+// ga / gz = d loss / d (alpha, rgb) flow outputs (activation and entropy-Jacobian terms already added), cE = the weight of the
+// log-det terms (- d_entropy / (P K)).  Accumulates d loss / d theta into gth and the base-Gaussian terms into gms.  Shared by
+// the fused tail kernel and the unfused flows_bwd_kernel, so both differentiate with the same arithmetic.
+__device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth)[84], float (&gms)[8], const f32x4 e, const float a_mean,
+                                              const float a_std, const float (&r_mean)[3], const float (&r_std)[3], float ga, float (&gz)[3],
+                                              const float cE, const bool valid) {
+    // ---- recompute the flows, keeping each step's input and tanh
+    float zin[4][3], tt[4][3], ain[4], ta[4];
+    float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};
+    float a = e[3] * a_std + a_mean;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const bool odd = f & 1;
+        zin[f][0] = z[0]; zin[f][1] = z[1]; zin[f][2] = z[2]; ain[f] = a;
+        const float zp0 = odd ? z[2] : z[0], zp1 = z[1], zp2 = odd ? z[0] : z[2];
+        const float pre0 = ((th[48 + f] * zp0 + th[(1 * 3 + 0) * 4 + f] * zp1) + th[(2 * 3 + 0) * 4 + f] * zp2) + th[60 + f];
+        const float pre1 = (th[52 + f] * zp1 + th[(2 * 3 + 1) * 4 + f] * zp2) + th[64 + f];
+        const float pre2 = th[56 + f] * zp2 + th[68 + f];
+        const float t0 = t_tanh(pre0), t1 = t_tanh(pre1), t2 = t_tanh(pre2);
+        tt[f][0] = t0; tt[f][1] = t1; tt[f][2] = t2;
+        const float u0 = (th[36 + f] * t0 + th[(0 * 3 + 1) * 4 + f] * t1) + th[(0 * 3 + 2) * 4 + f] * t2;
+        const float u1 = th[40 + f] * t1 + th[(1 * 3 + 2) * 4 + f] * t2;
+        const float u2 = th[44 + f] * t2;
+        z[0] = (odd ? u2 : u0) + z[0]; z[1] = u1 + z[1]; z[2] = (odd ? u0 : u2) + z[2];
+        ta[f] = t_tanh(th[76 + f] * a + th[80 + f]);
+        a = th[72 + f] * ta[f] + a;
+    }
+    // ---- adjoint, last flow first
+#pragma unroll
+    for (int f = 3; f >= 0; --f) {
+        const bool odd = f & 1;
+        const float zp0 = odd ? zin[f][2] : zin[f][0], zp1 = zin[f][1], zp2 = odd ? zin[f][0] : zin[f][2];
+        const float t0 = tt[f][0], t1 = tt[f][1], t2 = tt[f][2];
+        const float d1_0 = th[36 + f], d1_1 = th[40 + f], d1_2 = th[44 + f];
+        const float d2_0 = th[48 + f], d2_1 = th[52 + f], d2_2 = th[56 + f];
+        const float gu0 = odd ? gz[2] : gz[0], gu1 = gz[1], gu2 = odd ? gz[0] : gz[2];   // u = flip(z-update)
+        // u_i = sum_{j>=i} R1[i][j] t_j
+        float gt0 = d1_0 * gu0;
+        float gt1 = th[(0 * 3 + 1) * 4 + f] * gu0 + d1_1 * gu1;
+        float gt2 = th[(0 * 3 + 2) * 4 + f] * gu0 + th[(1 * 3 + 2) * 4 + f] * gu1 + d1_2 * gu2;
+        gth[36 + f] += gu0 * t0; gth[40 + f] += gu1 * t1; gth[44 + f] += gu2 * t2;
+        gth[(0 * 3 + 1) * 4 + f] += gu0 * t1; gth[(0 * 3 + 2) * 4 + f] += gu0 * t2; gth[(1 * 3 + 2) * 4 + f] += gu1 * t2;
+        // log-det: ld_i = log(|q_i| + 1e-8), q_i = (1 - t_i^2) d1_i d2_i + 1     (FLW:251-259)
+        if (cE != 0.f && valid) {
+            const float q0 = (1.f - t0 * t0) * (d1_0 * d2_0) + 1.f, q1 = (1.f - t1 * t1) * (d1_1 * d2_1) + 1.f,
+                        q2 = (1.f - t2 * t2) * (d1_2 * d2_2) + 1.f;
+            const float gq0 = cE * copysignf(1.f, q0) * t_rcp(fabsf(q0) + 1e-08f), gq1 = cE * copysignf(1.f, q1) * t_rcp(fabsf(q1) + 1e-08f),
+                        gq2 = cE * copysignf(1.f, q2) * t_rcp(fabsf(q2) + 1e-08f);
+            gt0 += gq0 * (-2.f * t0 * d1_0 * d2_0); gt1 += gq1 * (-2.f * t1 * d1_1 * d2_1); gt2 += gq2 * (-2.f * t2 * d1_2 * d2_2);
+            gth[36 + f] += gq0 * (1.f - t0 * t0) * d2_0; gth[40 + f] += gq1 * (1.f - t1 * t1) * d2_1; gth[44 + f] += gq2 * (1.f - t2 * t2) * d2_2;
+            gth[48 + f] += gq0 * (1.f - t0 * t0) * d1_0; gth[52 + f] += gq1 * (1.f - t1 * t1) * d1_1; gth[56 + f] += gq2 * (1.f - t2 * t2) * d1_2;
+        }
+        const float gp0 = gt0 * (1.f - t0 * t0), gp1 = gt1 * (1.f - t1 * t1), gp2 = gt2 * (1.f - t2 * t2);
+        gth[60 + f] += gp0; gth[64 + f] += gp1; gth[68 + f] += gp2;                         // b
+        // pre_i = sum_{j>=i} R2[i][j] zp_j,  R2[i][i] = d2_i,  R2[i][j>i] = D[j][i]
+        gth[48 + f] += gp0 * zp0; gth[52 + f] += gp1 * zp1; gth[56 + f] += gp2 * zp2;
+        gth[(1 * 3 + 0) * 4 + f] += gp0 * zp1; gth[(2 * 3 + 0) * 4 + f] += gp0 * zp2; gth[(2 * 3 + 1) * 4 + f] += gp1 * zp2;
+        const float gzp0 = d2_0 * gp0;
+        const float gzp1 = th[(1 * 3 + 0) * 4 + f] * gp0 + d2_1 * gp1;
+        const float gzp2 = th[(2 * 3 + 0) * 4 + f] * gp0 + th[(2 * 3 + 1) * 4 + f] * gp1 + d2_2 * gp2;
+        gz[0] += odd ? gzp2 : gzp0; gz[1] += gzp1; gz[2] += odd ? gzp0 : gzp2;
+        // alpha: a' = a + d1 tanh(d2 a + b)
+        {
+            const float d1 = th[72 + f], d2 = th[76 + f], tav = ta[f], ai = ain[f];
+            float gta = ga * d1;
+            gth[72 + f] += ga * tav;
+            if (cE != 0.f && valid) {
+                const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;
+                const float gq = cE * copysignf(1.f, q) * t_rcp(fabsf(q) + 1e-08f);
+                gta += gq * (-2.f * tav * d1 * d2);
+                gth[72 + f] += gq * (1.f - tav * tav) * d2;
+                gth[76 + f] += gq * (1.f - tav * tav) * d1;
+            }
+            const float gpa = gta * (1.f - tav * tav);
+            gth[80 + f] += gpa;
+            gth[76 + f] += gpa * ai;
+            ga += gpa * d2;
+        }
+    }
+    // base sample z0 = eps * std + mean  (MOD:239,251)
+    gms[0] += ga; gms[1] += ga * e[3];
+    gms[2] += gz[0]; gms[3] += gz[1]; gms[4] += gz[2];
+    gms[5] += gz[0] * e[0]; gms[6] += gz[1] * e[1]; gms[7] += gz[2] * e[2];
+}
+
+// One row of d loss / d theta (the pre-activation outputs of the flow-parameter heads), in the [P,128] layout of theta:
+// the diagonals were tanh-ed (MOD:341-348), the padding columns are written as zeros (the weight-gradient GEMM reads them).
+__device__ __forceinline__ void store_gtheta_row(float* __restrict__ row, const float (&th)[84], float (&gth)[84]) {
+#pragma unroll
+    for (int i = 36; i < 60; ++i) gth[i] *= (1.f - th[i] * th[i]);
+#pragma unroll
+    for (int i = 72; i < 80; ++i) gth[i] *= (1.f - th[i] * th[i]);
+    f32x4* gp = reinterpret_cast<f32x4*>(row);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = gth[q * 4]; v[1] = gth[q * 4 + 1]; v[2] = gth[q * 4 + 2]; v[3] = gth[q * 4 + 3]; gp[q] = v; }
+    f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+#pragma unroll
+    for (int q = 18; q < 24; ++q) gp[q] = zero;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { f32x4 v; v[0] = gth[72 + q * 4]; v[1] = gth[73 + q * 4]; v[2] = gth[74 + q * 4]; v[3] = gth[75 + q * 4]; gp[24 + q] = v; }
+#pragma unroll
+    for (int q = 27; q < 32; ++q) gp[q] = zero;
+}
+
 __global__ __launch_bounds__(kThreads)
 void tail_bwd_kernel(const TailArgs A) {
     __shared__ float carry[kWaves][kMaxK];
@@ -190,108 +296,158 @@ void tail_bwd_kernel(const TailArgs A) {
                            G2 * w * c2 * (1.f - c2) + cE * (1.f - 2.f * c2)};
             if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
 
-            // ---- recompute the flows, keeping each step's input and tanh
-            const f32x4 e = cur.e;
-            float zin[4][3], tt[4][3], ain[4], ta[4];
-            float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};
-            float a = e[3] * a_std + a_mean;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const bool odd = f & 1;
-                zin[f][0] = z[0]; zin[f][1] = z[1]; zin[f][2] = z[2]; ain[f] = a;
-                const float zp0 = odd ? z[2] : z[0], zp1 = z[1], zp2 = odd ? z[0] : z[2];
-                const float pre0 = ((th[48 + f] * zp0 + th[(1 * 3 + 0) * 4 + f] * zp1) + th[(2 * 3 + 0) * 4 + f] * zp2) + th[60 + f];
-                const float pre1 = (th[52 + f] * zp1 + th[(2 * 3 + 1) * 4 + f] * zp2) + th[64 + f];
-                const float pre2 = th[56 + f] * zp2 + th[68 + f];
-                const float t0 = t_tanh(pre0), t1 = t_tanh(pre1), t2 = t_tanh(pre2);
-                tt[f][0] = t0; tt[f][1] = t1; tt[f][2] = t2;
-                const float u0 = (th[36 + f] * t0 + th[(0 * 3 + 1) * 4 + f] * t1) + th[(0 * 3 + 2) * 4 + f] * t2;
-                const float u1 = th[40 + f] * t1 + th[(1 * 3 + 2) * 4 + f] * t2;
-                const float u2 = th[44 + f] * t2;
-                z[0] = (odd ? u2 : u0) + z[0]; z[1] = u1 + z[1]; z[2] = (odd ? u0 : u2) + z[2];
-                ta[f] = t_tanh(th[76 + f] * a + th[80 + f]);
-                a = th[72 + f] * ta[f] + a;
-            }
-            // ---- adjoint, last flow first
-#pragma unroll
-            for (int f = 3; f >= 0; --f) {
-                const bool odd = f & 1;
-                const float zp0 = odd ? zin[f][2] : zin[f][0], zp1 = zin[f][1], zp2 = odd ? zin[f][0] : zin[f][2];
-                const float t0 = tt[f][0], t1 = tt[f][1], t2 = tt[f][2];
-                const float d1_0 = th[36 + f], d1_1 = th[40 + f], d1_2 = th[44 + f];
-                const float d2_0 = th[48 + f], d2_1 = th[52 + f], d2_2 = th[56 + f];
-                const float gu0 = odd ? gz[2] : gz[0], gu1 = gz[1], gu2 = odd ? gz[0] : gz[2];   // u = flip(z-update)
-                // u_i = sum_{j>=i} R1[i][j] t_j
-                float gt0 = d1_0 * gu0;
-                float gt1 = th[(0 * 3 + 1) * 4 + f] * gu0 + d1_1 * gu1;
-                float gt2 = th[(0 * 3 + 2) * 4 + f] * gu0 + th[(1 * 3 + 2) * 4 + f] * gu1 + d1_2 * gu2;
-                gth[36 + f] += gu0 * t0; gth[40 + f] += gu1 * t1; gth[44 + f] += gu2 * t2;
-                gth[(0 * 3 + 1) * 4 + f] += gu0 * t1; gth[(0 * 3 + 2) * 4 + f] += gu0 * t2; gth[(1 * 3 + 2) * 4 + f] += gu1 * t2;
-                // log-det: ld_i = log(|q_i| + 1e-8), q_i = (1 - t_i^2) d1_i d2_i + 1     (FLW:251-259)
-                if (cE != 0.f && valid) {
-                    const float q0 = (1.f - t0 * t0) * (d1_0 * d2_0) + 1.f, q1 = (1.f - t1 * t1) * (d1_1 * d2_1) + 1.f,
-                                q2 = (1.f - t2 * t2) * (d1_2 * d2_2) + 1.f;
-                    const float gq0 = cE * copysignf(1.f, q0) * t_rcp(fabsf(q0) + 1e-08f), gq1 = cE * copysignf(1.f, q1) * t_rcp(fabsf(q1) + 1e-08f),
-                                gq2 = cE * copysignf(1.f, q2) * t_rcp(fabsf(q2) + 1e-08f);
-                    gt0 += gq0 * (-2.f * t0 * d1_0 * d2_0); gt1 += gq1 * (-2.f * t1 * d1_1 * d2_1); gt2 += gq2 * (-2.f * t2 * d1_2 * d2_2);
-                    gth[36 + f] += gq0 * (1.f - t0 * t0) * d2_0; gth[40 + f] += gq1 * (1.f - t1 * t1) * d2_1; gth[44 + f] += gq2 * (1.f - t2 * t2) * d2_2;
-                    gth[48 + f] += gq0 * (1.f - t0 * t0) * d1_0; gth[52 + f] += gq1 * (1.f - t1 * t1) * d1_1; gth[56 + f] += gq2 * (1.f - t2 * t2) * d1_2;
-                }
-                const float gp0 = gt0 * (1.f - t0 * t0), gp1 = gt1 * (1.f - t1 * t1), gp2 = gt2 * (1.f - t2 * t2);
-                gth[60 + f] += gp0; gth[64 + f] += gp1; gth[68 + f] += gp2;                         // b
-                // pre_i = sum_{j>=i} R2[i][j] zp_j,  R2[i][i] = d2_i,  R2[i][j>i] = D[j][i]
-                gth[48 + f] += gp0 * zp0; gth[52 + f] += gp1 * zp1; gth[56 + f] += gp2 * zp2;
-                gth[(1 * 3 + 0) * 4 + f] += gp0 * zp1; gth[(2 * 3 + 0) * 4 + f] += gp0 * zp2; gth[(2 * 3 + 1) * 4 + f] += gp1 * zp2;
-                const float gzp0 = d2_0 * gp0;
-                const float gzp1 = th[(1 * 3 + 0) * 4 + f] * gp0 + d2_1 * gp1;
-                const float gzp2 = th[(2 * 3 + 0) * 4 + f] * gp0 + th[(2 * 3 + 1) * 4 + f] * gp1 + d2_2 * gp2;
-                gz[0] += odd ? gzp2 : gzp0; gz[1] += gzp1; gz[2] += odd ? gzp0 : gzp2;
-                // alpha: a' = a + d1 tanh(d2 a + b)
-                {
-                    const float d1 = th[72 + f], d2 = th[76 + f], tav = ta[f], ai = ain[f];
-                    float gta = ga * d1;
-                    gth[72 + f] += ga * tav;
-                    if (cE != 0.f && valid) {
-                        const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;
-                        const float gq = cE * copysignf(1.f, q) * t_rcp(fabsf(q) + 1e-08f);
-                        gta += gq * (-2.f * tav * d1 * d2);
-                        gth[72 + f] += gq * (1.f - tav * tav) * d2;
-                        gth[76 + f] += gq * (1.f - tav * tav) * d1;
-                    }
-                    const float gpa = gta * (1.f - tav * tav);
-                    gth[80 + f] += gpa;
-                    gth[76 + f] += gpa * ai;
-                    ga += gpa * d2;
-                }
-            }
-            // base sample z0 = eps * std + mean  (MOD:239,251)
-            gms[0] += ga; gms[1] += ga * e[3];
-            gms[2] += gz[0]; gms[3] += gz[1]; gms[4] += gz[2];
-            gms[5] += gz[0] * e[0]; gms[6] += gz[1] * e[1]; gms[7] += gz[2] * e[2];
+            flows_adjoint(th, gth, gms, cur.e, a_mean, a_std, r_mean, r_std, ga, gz, cE, valid);
         }
-        // diagonals were tanh-ed (MOD:341-348): gradient w.r.t. the linear head output
-#pragma unroll
-        for (int i = 36; i < 60; ++i) gth[i] *= (1.f - th[i] * th[i]);
-#pragma unroll
-        for (int i = 72; i < 80; ++i) gth[i] *= (1.f - th[i] * th[i]);
-        if (valid) {
-            f32x4* gp = reinterpret_cast<f32x4*>(g_theta_out + p * kThetaAll);
-#pragma unroll
-            for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = gth[q * 4]; v[1] = gth[q * 4 + 1]; v[2] = gth[q * 4 + 2]; v[3] = gth[q * 4 + 3]; gp[q] = v; }
-            f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
-#pragma unroll
-            for (int q = 18; q < 24; ++q) gp[q] = zero;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { f32x4 v; v[0] = gth[72 + q * 4]; v[1] = gth[73 + q * 4]; v[2] = gth[74 + q * 4]; v[3] = gth[75 + q * 4]; gp[24 + q] = v; }
-#pragma unroll
-            for (int q = 27; q < 32; ++q) gp[q] = zero;
-        }
+        if (valid) store_gtheta_row(g_theta_out + p * kThetaAll, th, gth);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) gms[i] = wave_sum(gms[i]);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) A.gms_partials[unit * 8 + i] = gms[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2b. The UNFUSED seam (the reference's NeRF_Flows.forward and raw2outputs are separately differentiable, so a caller-supplied
+//     network_query_fn trains): the tail kernel's two halves as standalone kernels with the same arithmetic.
+//
+// flows_bwd_kernel: adjoint of the K flows + the entropy terms of NeRF_Flows.forward (MOD:225-291) given d loss / d raw [P,K,4].
+// lane = point; every latent of a point in one lane, so g_theta needs no partial sums.
+__global__ __launch_bounds__(kThreads)
+void flows_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ theta, const float* __restrict__ eps, const float* __restrict__ flat,
+                      const float* __restrict__ d_raw, const float* __restrict__ d_ent, int64_t P, int K, float* __restrict__ g_theta,
+                      float* __restrict__ gms_partials) {
+    const int lane = lane_id_opaque(), wave = wave_id();
+    const int64_t pi = (int64_t)blockIdx.x * kThreads + wave * 64 + lane;
+    const bool valid = pi < P;
+    const int64_t p = valid ? pi : 0;
+    const float cE = -((d_ent != nullptr) ? d_ent[0] : 0.f) / (float)((double)P * (double)K);
+    const float a_mean = flat[0], a_std = flat[1];
+    const float r_mean[3] = {flat[2], flat[3], flat[4]};
+    const float r_std[3] = {flat[5], flat[6], flat[7]};
+    float th[84], gth[84], gms[8];
+    {
+        const f32x4* tp = reinterpret_cast<const f32x4*>(theta + p * kThetaAll);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) { const f32x4 v = tp[q]; th[q * 4] = v[0]; th[q * 4 + 1] = v[1]; th[q * 4 + 2] = v[2]; th[q * 4 + 3] = v[3]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const f32x4 v = tp[kThetaRgb / 4 + q]; th[72 + q * 4] = v[0]; th[73 + q * 4] = v[1]; th[74 + q * 4] = v[2]; th[75 + q * 4] = v[3]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 84; ++i) gth[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gms[i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + (p * K + k) * 4);
+        f32x4 g; g[0] = g[1] = g[2] = g[3] = 0.f;
+        if (d_raw != nullptr) g = *reinterpret_cast<const f32x4*>(d_raw + (p * K + k) * 4);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(eps + k * 4);
+        const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]), sg = t_sigmoid(rv[3]);
+        float ga = g[3] + cE * (1.f - sg);                                     // + d(-mean(a - softplus a))  MOD:263
+        float gz[3] = {g[0] + cE * (1.f - 2.f * c0), g[1] + cE * (1.f - 2.f * c1), g[2] + cE * (1.f - 2.f * c2)};   // MOD:278
+        if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
+        flows_adjoint(th, gth, gms, e, a_mean, a_std, r_mean, r_std, ga, gz, cE, valid);
+    }
+    if (valid) store_gtheta_row(g_theta + p * kThetaAll, th, gth);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gms[i] = wave_sum(gms[i]);
+    if (lane == 0) {
+        const int64_t row = (int64_t)blockIdx.x * kWaves + wave;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gms_partials[row * 8 + i] = gms[i];
+    }
+}
+
+// composite_bwd_kernel: adjoint of raw2outputs (RUN:411-454) as a stateless call.  One wave per ray, lane = sample; the forward
+// is recomputed with the forward kernels' own arithmetic (softplus / exp / wave product scan with a per-chunk carry), the carry
+// of every 64-sample chunk is parked in LDS, then the chunks are walked back to front exactly like the fused tail kernel.
+//   d loss / d w_s = sum_c G_c c_s + Gd' z_s + Ga + Gw_s     with  Gd' = Gd + Gdisp d disp / d depth,
+//   Ga = Gdisp d disp / d acc - [white_bkgd] sum_c G_c       (disp = 1 / max(2e-10, depth / (acc + 1e-10) + 1e-10), RUN:448)
+constexpr int kCompMaxChunks = 64;            // S <= 4096
+__global__ __launch_bounds__(kThreads)
+void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t N, int S,
+                          int K, int white_bkgd, const float* __restrict__ d_rgb, const float* __restrict__ d_disp,
+                          const float* __restrict__ d_depth, const float* __restrict__ d_weights, float* __restrict__ d_raw) {
+    __shared__ float carryT[kWaves][kCompMaxChunks];
+    const int lane = lane_id_opaque(), wave = wave_id();
+    const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+    if (ray >= N) return;
+    const float* d = rays_d + ray * 3;
+    const float dnorm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zr = z_vals + ray * (int64_t)S;
+    const int nch = (S + 63) / 64;
+    for (int k = 0; k < K; ++k) {
+        // ---- forward sums of this latent (depth, acc) and the transmittance entering every chunk
+        float car = 1.f, ad = 0.f, aa = 0.f;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int s = ch * 64 + lane;
+            const bool valid = s < S;
+            float zv = 0.f, alpha = 0.f;
+            if (valid) {
+                zv = zr[s];
+                const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
+                alpha = 1.f - expf(-softplus_f(raw[((ray * S + s) * (int64_t)K + k) * 4 + 3]) * (dz * dnorm));
+            }
+            const float incl = wave_scan_mul((1.f - alpha) + 1e-10f);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) { excl = 1.f; carryT[wave][ch] = car; }
+            const float wgt = alpha * (car * excl);
+            ad += wave_sum(wgt * zv);
+            aa += wave_sum(wgt);
+            car *= __shfl(incl, 63, 64);
+        }
+        const float G0 = d_rgb[ray * 3 * (int64_t)K + 0 * K + k], G1 = d_rgb[ray * 3 * (int64_t)K + 1 * K + k], G2 = d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
+        float Gd = (d_depth != nullptr) ? d_depth[ray * (int64_t)K + k] : 0.f;
+        float Ga = white_bkgd ? -(G0 + G1 + G2) : 0.f;
+        if (d_disp != nullptr) {
+            const float q = ad / (aa + 1e-10f) + 1e-10f;
+            if (q > 1e-10f + 1e-10f) {                                         // torch.max routes the gradient to the larger argument
+                const float gq = -d_disp[ray * (int64_t)K + k] / (q * q);
+                Gd += gq / (aa + 1e-10f);
+                Ga += gq * (-ad / ((aa + 1e-10f) * (aa + 1e-10f)));
+            }
+        }
+        // ---- back to front: suffix sums of g w as a reverse wave scan + a carry (see tail_bwd_kernel)
+        float sufcar = 0.f;
+        for (int ch = nch - 1; ch >= 0; --ch) {
+            const int s = ch * 64 + lane;
+            const bool valid = s < S;
+            const int64_t idx = (ray * S + (valid ? s : 0)) * (int64_t)K + k;
+            f32x4 rv; rv[0] = rv[1] = rv[2] = rv[3] = 0.f;
+            float zv = 0.f, dist = 0.f, alpha = 0.f;
+            if (valid) {
+                rv = *reinterpret_cast<const f32x4*>(raw + idx * 4);
+                zv = zr[s];
+                const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
+                dist = dz * dnorm;
+                alpha = 1.f - expf(-softplus_f(rv[3]) * dist);
+            }
+            const float xk = (1.f - alpha) + 1e-10f;
+            const float incl_m = wave_scan_mul(xk);
+            float excl_m = __shfl_up(incl_m, 1, 64);
+            if (lane == 0) excl_m = 1.f;
+            const float Tt = carryT[wave][ch] * excl_m;
+            const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
+            const float w = alpha * Tt;
+            float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
+            g += Ga;
+            if (d_weights != nullptr && valid) g += d_weights[idx];
+            const float gw = valid ? g * w : 0.f;
+            const float incl = wave_scan_add_rev(gw);
+            float excl = __shfl_down(incl, 1, 64);
+            if (lane == 63) excl = 0.f;
+            const float suffix = excl + sufcar;
+            sufcar += __shfl(incl, 0, 64);
+            const float dalpha = g * Tt - suffix * t_rcp(xk);
+            const float sg = t_sigmoid(rv[3]);                                 // softplus'
+            if (valid) {
+                f32x4 o;
+                o[0] = G0 * w * c0 * (1.f - c0); o[1] = G1 * w * c1 * (1.f - c1); o[2] = G2 * w * c2 * (1.f - c2);
+                o[3] = dalpha * (1.f - alpha) * dist * sg;
+                *reinterpret_cast<f32x4*>(d_raw + idx * 4) = o;
+            }
+        }
     }
 }
 
@@ -1177,6 +1333,38 @@ static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, 
     }
 }
 
+// Split counts of the small jobs.  The launch is HBM-bound (a block streams 32 x (a_ld + b_ld) floats per stage), two
+// workgroups fit a CU, and with a fixed 128 splits per tile the 10 tiles of the default network made 1280 blocks = 2.5
+// rounds of 512 slots: the last half round ran on a half-empty chip.  Instead the launch is ONE round - 2 n_cu blocks that
+// all start together - and a tile's share of them is proportional to the bytes it streams per point (+ a fixed per-stage
+// cost), so they also end together; fewer splits are fewer partial slots for the reduction to read, too.
+static int small_stage_cols(const DwTile& t) {
+    const int gk = t.gk, gn = 8 / gk, tn = std::min(32 * gn, 128), tk = 32 * gk;
+    return pad_to(std::min(tn, t.N - t.n0), 32) + pad_to(std::min(tk, t.K - t.k0), 32);
+}
+static void balance_small_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P) {
+    if (tiles.empty()) return;
+    int cap = kDwSlots;
+    while (cap > 1 && P / cap < 512) cap >>= 1;              // at least 512 points per block
+#ifdef CFN_DS_FIXED_SPLITS
+    for (DwTile& t : tiles) t.nsplit = cap;
+    return;
+#endif
+    auto cost = [](const DwTile& t) { return (double)(small_stage_cols(t) + 32); };
+    double total = 0;
+    for (const DwTile& t : tiles) total += cost(t);
+    const int slots = 2 * n_cu;
+    int used = 0;
+    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(slots * cost(t) / total))); used += t.nsplit; }
+    while (used < slots) {                                   // the remaining slots go to the tiles whose blocks are longest
+        DwTile* best = nullptr;
+        for (DwTile& t : tiles)
+            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
+        if (!best) break;
+        ++best->nsplit; ++used;
+    }
+}
+
 // The whole host-side plan of the weight-gradient launches for one workspace binding: tiles, per-tile splits, blocks
 // (2 x 4 tiles first, then the 1 x 8 tiles), small-job blocks and the per-tensor slot counts of the reduction.
 // Returns nullptr or the reason it cannot be built.
@@ -1188,9 +1376,7 @@ static const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, cons
     // blocks are short and run several per CU)
     const int kMaxSplit = 64;
     balance_big_splits(Hs.tiles, n_cu, P, kMaxSplit);
-    int ns_small = kDwSlots;
-    while (ns_small > 1 && P / ns_small < 512) ns_small >>= 1;
-    for (DwTile& t : Hs.tiles_small) t.nsplit = ns_small;
+    balance_small_splits(Hs.tiles_small, n_cu, P);
     make_blocks(Hs.blocks, Hs.tiles, P, kDwRows);              // one launch: longest blocks first, whatever their arrangement
     *n_blocks_wide = 0;
     for (const DwBlock& b : Hs.blocks) *n_blocks_wide += Hs.tiles[b.tile].gk == 0;
@@ -1258,16 +1444,20 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
     return CFNERF_OK;
 }
 
-int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
-                      const float* d_entropy, float* grad_flat, cfnerf_stream s) {
-    if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
+// Backward of the stashed forward, shared by the fused (cfnerf_render_bwd: rays, `d_out` = d_rgb_map) and the unfused
+// (cfnerf_network_bwd: points, `d_out` = d_raw) entry points: first stage -> g_theta, then backward-data and the weight gradients.
+static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generation, const float* d_out, const float* d_depth_map,
+                            const float* d_entropy, float* grad_flat, cfnerf_stream s) {
     Stash& q = m->stash;
-    if (!q.valid) return bfail(CFNERF_E_INVALID, "no stashed forward: call cfnerf_render_fwd with CFNERF_F_STASH first");
+    if (!q.valid) return bfail(CFNERF_E_INVALID, "no stashed forward: call cfnerf_render_fwd / cfnerf_network_fwd with CFNERF_F_STASH first");
     if (stash_generation != q.generation)
         return bfail(CFNERF_E_INVALID, "stale stash: this backward belongs to STASH forward #%llu but the model's one stash now holds "
                      "forward #%llu (a later grad-enabled forward overwrote it; run each backward before the next STASH forward)",
                      (unsigned long long)stash_generation, (unsigned long long)q.generation);
-    if (q.S > 4096) return bfail(CFNERF_E_UNSUPPORTED, "backward supports S <= 4096");
+    if (q.points != points)
+        return bfail(CFNERF_E_INVALID, points ? "the stashed forward is a cfnerf_render_fwd (ray) launch: differentiate it with cfnerf_render_bwd"
+                                              : "the stashed forward is a cfnerf_network_fwd (points) launch: differentiate it with cfnerf_network_bwd");
+    if (!points && q.S > 4096) return bfail(CFNERF_E_UNSUPPORTED, "backward supports S <= 4096");
     hipStream_t st = (hipStream_t)s;
     if (int rc = ensure_bwd_plan(m)) return rc;
     BwdPlan& B = m->bwd;
@@ -1301,20 +1491,29 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     }
     const DwHost& Hc = B.host[B.cur];
 
-    // ---- 1. tail
-    TailArgs ta{};
-    ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
-    ta.d_rgb = d_rgb_map; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
-    ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
-    // k-parts: the kernel runs ONE wave per SIMD, so split only while the waves still fit in one round (measured: a
-    // second round costs more than the shorter k-loops save); at most kTailParts and never more than K / 2
+    // ---- 1. first stage -> g_theta (+ base-Gaussian partials)
     int ksplit = 1;
-    while (ksplit < kTailParts && ksplit * 2 <= q.K && N * ksplit * 2 <= (int64_t)m->n_cu * 4) ksplit *= 2;
-    ta.ksplit = ksplit;
+    int64_t gms_rows = 0;
     if (m->timing == 1) BHIP(hipEventRecord(m->ev0[1], st));
-    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
+    if (!points) {
+        TailArgs ta{};
+        ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
+        ta.d_rgb = d_out; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
+        ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
+        // k-parts: the kernel runs ONE wave per SIMD, so split only while the waves still fit in one round (measured: a
+        // second round costs more than the shorter k-loops save); at most kTailParts and never more than K / 2
+        while (ksplit < kTailParts && ksplit * 2 <= q.K && N * ksplit * 2 <= (int64_t)m->n_cu * 4) ksplit *= 2;
+        ta.ksplit = ksplit;
+        gms_rows = N * ksplit;
+        hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);
+    } else {
+        const unsigned grid = (unsigned)((P + kThreads - 1) / kThreads);
+        gms_rows = (int64_t)grid * kWaves;                       // one row per wave (waves past P contribute zeros)
+        hipLaunchKernelGGL(flows_bwd_kernel, dim3(grid), dim3(kThreads), 0, st, q.raw, q.theta, m->d_eps, m->flat, d_out, d_entropy, P, q.K,
+                           q.g_theta, q.gms);
+    }
     BHIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, N * ksplit, m->flat, d_entropy, grad_flat);
+    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, gms_rows, m->flat, d_entropy, grad_flat);
     BHIP(hipGetLastError());
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[1], st));
 
@@ -1323,7 +1522,7 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     BwdArgs ba{};
     ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_parts = ksplit; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
-    ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;
+    ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;      // (points: ONE "ray" of S = P samples)
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
     if (m->timing == 1) BHIP(hipEventRecord(m->ev0[2], st));
@@ -1359,6 +1558,32 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
     hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 0);
     BHIP(hipGetLastError());
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[3], st));
+    return CFNERF_OK;
+}
+
+int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+                      const float* d_entropy, float* grad_flat, cfnerf_stream s) {
+    if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
+    return backward_stashed(m, false, stash_generation, d_rgb_map, d_depth_map, d_entropy, grad_flat, s);
+}
+
+int cfnerf_network_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_raw, const float* d_entropy, float* grad_flat,
+                       cfnerf_stream s) {
+    if (!m || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
+    if (!d_raw && !d_entropy) return bfail(CFNERF_E_INVALID, "d_raw and d_entropy are both NULL: nothing to differentiate");
+    return backward_stashed(m, true, stash_generation, d_raw, nullptr, d_entropy, grad_flat, s);
+}
+
+int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K, int white_bkgd,
+                         const float* d_rgb_map, const float* d_disp_map, const float* d_depth_map, const float* d_weights, float* d_raw,
+                         cfnerf_stream s) {
+    if (N < 0 || S < 1 || K < 1) return bfail(CFNERF_E_INVALID, "bad N/S/K");
+    if (S > 64 * kCompMaxChunks) return bfail(CFNERF_E_UNSUPPORTED, "cfnerf_composite_bwd supports S <= %d", 64 * kCompMaxChunks);
+    if (N == 0) return CFNERF_OK;
+    if (!raw || !z_vals || !rays_d || !d_rgb_map || !d_raw) return bfail(CFNERF_E_INVALID, "NULL argument");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, (hipStream_t)s, raw, z_vals, rays_d, N, S,
+                       K, white_bkgd, d_rgb_map, d_disp_map, d_depth_map, d_weights, d_raw);
+    BHIP(hipGetLastError());
     return CFNERF_OK;
 }
 

@@ -442,7 +442,9 @@ __device__ __forceinline__ float enc_channel(const float* v, int c) {
     if (c < 3) return v[c];
     const int q = (c - 3) / 3, d = (c - 3) - 3 * q;       // q = 2*f + (0 sin | 1 cos)
     const float a = v[d] * (float)(1 << (q >> 1));
-    return (q & 1) ? cosf(a) : sinf(a);
+    float sv, cv;
+    sincosf(a, &sv, &cv);          // the SAME routine as the fused kernel's encode_tile: fused and unfused encodings are bit-identical
+    return (q & 1) ? cv : sv;
 }
 
 // ---- the conditional triangular Sylvester flows for one (point, latent sample) ------------------

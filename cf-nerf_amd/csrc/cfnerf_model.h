@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -56,6 +57,7 @@ struct Stash {
     int64_t n_tiles = 0;
     int64_t N = 0; int S = 0, K = 0, flags = 0;
     bool valid = false;             // a STASH forward has filled it
+    bool points = false;            // ... in points mode (cfnerf_network_fwd: N = 1, S = P): differentiated by cfnerf_network_bwd
     uint64_t generation = 0;        // bumped by every STASH forward; cfnerf_render_bwd checks the caller's copy against it
 
     // binding
@@ -84,7 +86,7 @@ struct Stash {
         take(&t->theta, (size_t)P * kThetaAll, 4); take(&t->z, (size_t)P + 1, 4); take(&t->raw, (size_t)P * k * 4, 4);
         take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
         take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
-        take(&t->gms, (size_t)(n * kTailParts + 8) * 8, 4);
+        take(&t->gms, (size_t)(std::max<int64_t>(n * kTailParts, tiles) + 8) * 8, 4);      // rays * k-parts (fused tail) or waves of points (flows_bwd)
         take(&t->g_theta, (size_t)kTailParts * P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);
         take(&t->g_ha, (size_t)P * c.h_alpha_size, 4); take(&t->g_v, (size_t)P * (W / 2), 4);
         take(&t->g_feat, (size_t)P * W, 4); take(&t->g_h, (size_t)D * P * W, 4);

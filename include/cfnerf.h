@@ -151,7 +151,9 @@ int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_ran
                       const float* u, int64_t N, int S, int K, int N_importance, float* z_out, cfnerf_stream s);
 
 /* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]
- * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].                   */
+ * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].  With CFNERF_F_STASH (implies TRAIN) the
+ * activations are kept for cfnerf_network_bwd (the model's ONE stash, bound as one "ray" of P samples: size the workspace
+ * with cfnerf_workspace_bytes(cfg, 1, P, K)).                                                     */
 int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags,
                        float* raw, float* entropy_out, cfnerf_stream s);
 
@@ -191,6 +193,24 @@ uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
  * means 0.  grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.             */
 int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
                       const float* d_entropy, float* grad_flat, cfnerf_stream s);
+
+/* ---- the UNFUSED seam, differentiable like the reference's ---------------------------------------------------------
+ * In the reference NeRF_Flows.forward (MOD:188-291) and raw2outputs (RUN:411-454) are ordinary autograd graphs, so a caller
+ * that injects its own network_query_fn (RUN:382-394, called at RUN:538) still trains.  These two entry points are the
+ * tail of cfnerf_render_bwd split at `raw`, with the same arithmetic.
+ *
+ * replaces: loss.backward() through NeRF_Flows.forward for the cfnerf_network_fwd(... CFNERF_F_STASH ...) whose generation
+ * is `stash_generation`.  d_raw [P,K,4] = d loss / d raw (NULL = zeros), d_entropy = ONE device float, d loss /
+ * d loss_entropy (NULL = 0).  grad_flat [param_count] is OVERWRITTEN.  Gradients with respect to the inputs x are not
+ * produced (the reference's sample points are not parameters).                                                         */
+int cfnerf_network_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_raw, const float* d_entropy,
+                       float* grad_flat, cfnerf_stream s);
+/* replaces: loss.backward() through raw2outputs(raw, z_vals, rays_d) RUN:411-454, stateless: the forward is recomputed from
+ * raw [N,S,K,4], z_vals [N,S], rays_d [N,3].  d_rgb_map [N,3,K]; d_disp_map [N,K], d_depth_map [N,K], d_weights [N,S,K] may
+ * be NULL (= zeros).  Writes d_raw [N,S,K,4] = d loss / d raw.  S <= 4096.                                               */
+int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K, int white_bkgd,
+                         const float* d_rgb_map, const float* d_disp_map, const float* d_depth_map, const float* d_weights,
+                         float* d_raw, cfnerf_stream s);
 
 /* ---- overlap of the multi-GPU gradient exchange with the end of the backward --------------------------------
  * replaces: nothing in the reference (its nn.DataParallel, RUN:330, gathers gradients inside autograd).  Most of

@@ -1,0 +1,258 @@
+"""-m gpu: the UNFUSED seam is differentiable like the reference's.  In the reference NeRF_Flows.forward (MOD:188-291) and
+raw2outputs (RUN:411-454) are autograd graphs, so a caller-injected network_query_fn (RUN:382-394, used at RUN:538) trains.
+Here they are autograd nodes over cfnerf_network_fwd/_bwd and cfnerf_composite_fwd/_bwd; the gradients they give must be the
+fused path's (same kernels' arithmetic, split at `raw`) and the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+import cfnerf_amd
+from oracle import cfnerf_oracle as O
+from util_hip import build_model, close, fern_rays, grad_close_tight, hip_relu_masks, oracle_train_step_on_hip_masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel_to_max(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------- raw2outputs backward (RUN:411-454)
+@pytest.mark.parametrize("N,S,K,wb", [(6, 128, 4, False), (5, 128, 3, True), (4, 70, 2, False), (3, 200, 5, True), (2, 2, 1, False)])
+def test_composite_backward_vs_oracle_autograd(N, S, K, wb):
+    """every output of raw2outputs is differentiable with respect to raw: rgb_map, disp_map, weights, depth_map - incl. an
+    opaque and an empty ray, ragged sample counts, the white-background branch"""
+    rng = np.random.default_rng(100 * N + S + K)
+    raw = torch.tensor(rng.standard_normal((N, S, K, 4)) * 1.5, dtype=torch.float32)
+    raw[0, :, :, 3] = 25.0                                   # softplus threshold branch
+    if S > 4:
+        raw[0, S // 2, :, 3] = 2000.0                        # one fully opaque sample: alpha = 1 in fp32, cumprod factor 1e-10
+    if N > 1:
+        raw[1, :, :, 3] = -30.0                              # empty ray
+    z = torch.sort(torch.tensor(rng.uniform(0.05, 1.0, (N, S)), dtype=torch.float32), -1).values
+    d = torch.tensor(rng.standard_normal((N, 3)), dtype=torch.float32)
+    G = [torch.tensor(rng.standard_normal(s), dtype=torch.float32) for s in ((N, 3, K), (N, K), (N, S, K), (N, K))]
+    if N > 1:
+        # disp of an EMPTY ray is 1 / max(2e-10, 0 / (0 + 1e-10) + 1e-10): fp32 sits on the clamp (alpha is exactly 0), fp64 just off
+        # it (alpha ~ 1e-14) with a 1e6-fold amplification - no gradient is defined there; the reference never differentiates disp
+        G[1][1] = 0
+    for use in ((1, 0, 0, 0), (1, 0, 0, 1), (1, 1, 1, 1)):   # rgb only (the training loss) | + depth | every output
+        r64 = raw.double().requires_grad_(True)
+        outs = O.raw2outputs(r64, z.double(), d.double(), wb)
+        loss = sum((o * g.double()).sum() for o, g, u in zip(outs, G, use) if u)
+        (ref,) = torch.autograd.grad(loss, r64)
+        rg = raw.to(DEV).requires_grad_(True)
+        outs_h = cfnerf_amd.raw2outputs(rg, z.to(DEV), d.to(DEV), 0, wb)
+        for o, oo, name in zip(outs_h, outs, ("rgb_map", "disp_map", "weights", "depth_map")):
+            if name != "disp_map":
+                close(o, oo.float(), what=name)
+        loss_h = sum((o * g.to(DEV)).sum() for o, g, u in zip(outs_h, G, use) if u)
+        (got,) = torch.autograd.grad(loss_h, rg)
+        # fp32 against the fp64 oracle: the adjoint of a transmittance product carries the forward's own rounding
+        assert _rel_to_max(got.cpu(), ref) <= 2e-5, (use, _rel_to_max(got.cpu(), ref))
+        close(got.cpu(), ref.float(), atol=2e-5 * float(ref.abs().max()), rtol=2e-3, what=f"d_raw {use}")
+
+
+def test_composite_backward_matches_torch_autograd_contract():
+    """no gradient requested -> zeros; raw without requires_grad -> plain tensors (no graph), like any torch function"""
+    raw = torch.randn(3, 128, 2, 4, device=DEV)
+    z = torch.sort(torch.rand(3, 128, device=DEV), -1).values
+    d = torch.randn(3, 3, device=DEV)
+    out = cfnerf_amd.raw2outputs(raw, z, d)
+    assert not any(o.requires_grad for o in out)
+    rg = raw.clone().requires_grad_(True)
+    out = cfnerf_amd.raw2outputs(rg, z, d)
+    assert all(o.requires_grad for o in out)
+    (g,) = torch.autograd.grad(out[3].sum(), rg)
+    assert g.shape == raw.shape and torch.isfinite(g).all() and float(g[..., :3].abs().max()) == 0.0     # depth does not see the colours
+
+
+# ---------------------------------------------------------------- NeRF_Flows.forward backward (MOD:188-291)
+@pytest.mark.parametrize("W,K,P,ha", [(256, 4, 1000, 32), (128, 3, 130, 32), (64, 8, 64, 32), (512, 2, 96, 64), (256, 16, 257, 32)])
+def test_network_backward_vs_oracle_autograd(W, K, P, ha):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=ha)
+    _, _, _, model, p, _ = build_model(cfg, 900 + W + K)
+    net = model.module
+    rng = np.random.default_rng(P + K)
+    pts = torch.tensor(rng.uniform(-1, 1, (P, 3)), dtype=torch.float32)
+    dirs = torch.nn.functional.normalize(torch.tensor(rng.standard_normal((P, 3)), dtype=torch.float32), dim=-1)
+    x = torch.cat([O.embed(pts, cfg.multires), O.embed(dirs, cfg.multires_views)], -1)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    G = torch.tensor(rng.standard_normal((P, K, 4)), dtype=torch.float32) / (P * K)
+    cE = 0.3
+    net.flat.grad = None
+    raw, ent = net(x.to(DEV), False, False, eps_alpha=ea, eps_rgb=er)
+    assert raw.requires_grad and list(ent.shape) == [P, K, 1]
+    loss = (raw * G.to(DEV)).sum() + cE * ent.mean()
+    loss.backward()
+    grad = net.flat.grad.detach().cpu()
+    # the oracle on the ReLU masks the HIP forward took (tests/util_hip.py)
+    acts, masks = hip_relu_masks(net, P)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    with O.relu_override(masks=masks):
+        raw_o, ent_o = O.nerf_flows_forward(pr, x, ea, er, cfg, False)
+    close(raw, raw_o, what="raw")
+    close(ent.mean(), ent_o, what="entropy")
+    ((raw_o * G).sum() + cE * ent_o).backward()
+    n = 0
+    for key, (off, cnt) in net.layout.items():
+        if pr[key].grad is None:
+            assert not grad[off:off + cnt].any(), key
+        else:
+            grad_close_tight(grad[off:off + cnt].reshape(pr[key].shape), pr[key].grad.numpy(), f"grad {key}")
+            n += 1
+    assert n >= 30
+
+
+def test_entropy_only_and_raw_only_gradients():
+    """either cotangent may be absent (autograd hands None / zeros): d_raw = NULL or d_entropy = NULL at the C ABI"""
+    cfg = O.OracleCfg(netwidth=64, K_samples=3)
+    _, _, _, model, p, _ = build_model(cfg, 5)
+    net = model.module
+    x = torch.randn(200, 90, device=DEV) * 0.5
+    ea, er = torch.randn(3, 1), torch.randn(3, 3)
+    grads = []
+    for pick in ("raw", "ent", "both"):
+        net.flat.grad = None
+        raw, ent = net(x, False, False, eps_alpha=ea, eps_rgb=er)
+        loss = (raw.sum() if pick != "ent" else 0.) + (ent.mean() if pick != "raw" else 0.)
+        loss.backward()
+        grads.append(net.flat.grad.clone())
+    assert _rel_to_max(grads[0] + grads[1], grads[2]) <= 1e-5
+
+
+# ---------------------------------------------------------------- training through a caller-supplied network_query_fn
+def _problem(W=256, K=4, N=40, seed=77, **over):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K)
+    args, kw_train, kw_test, model, p, _ = build_model(cfg, seed, **over)
+    rng = np.random.default_rng(3)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    return cfg, args, kw_train, model, p, rays, (H, Wd, focal), t_rand, ea, er, target
+
+
+def _loss_like_the_reference(rgb, extras, target, K, beta1):
+    """RUN:1026-1050 in torch, exactly as a user of the reference's loop would write it"""
+    return O.train_loss(rgb, target, extras["loss_entropy"].mean(), K, beta1)["loss"]
+
+
+@pytest.mark.parametrize("W,K,N,wb", [(256, 4, 40, False), (128, 8, 24, True), (64, 2, 70, False)])
+def test_training_through_a_custom_query_fn_gives_the_fused_gradients_and_the_oracles(W, K, N, wb):
+    beta1 = 0.05
+    cfg, args, kw_train, model, p, rays, (H, Wd, focal), t_rand, ea, er, target = _problem(W, K, N, white_bkgd=wb)
+    net = model.module
+    embed_fn, _ = cfnerf_amd.get_embedder(10)
+    embeddirs_fn, _ = cfnerf_amd.get_embedder(4)
+    calls = []
+
+    def my_query_fn(inputs, viewdirs, network_fn, is_val, is_test):          # what RUN:333-336 builds, written by the caller
+        calls.append(inputs.shape)
+        return cfnerf_amd.run_network(inputs, viewdirs, network_fn, is_val, is_test, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                                      netchunk=1024 * 64)
+    common = dict(rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er)
+    # (a) the fused launch under autograd
+    net.flat.grad = None
+    rgb_f, _, _, ex_f = cfnerf_amd.render(H, Wd, focal, **common, **kw_train)
+    loss_f = _loss_like_the_reference(rgb_f, ex_f, target.to(DEV), K, beta1)
+    loss_f.backward()
+    g_fused = net.flat.grad.clone()
+    # (b) the caller's query fn: sample kernel -> embed kernels -> NeRF_Flows node -> raw2outputs node
+    net.flat.grad = None
+    rgb_u, _, _, ex_u = cfnerf_amd.render(H, Wd, focal, **common, **dict(kw_train, network_query_fn=my_query_fn))
+    assert calls and rgb_u.requires_grad
+    loss_u = _loss_like_the_reference(rgb_u, ex_u, target.to(DEV), K, beta1)
+    loss_u.backward()
+    g_unf = net.flat.grad.clone()
+    close(rgb_u, rgb_f, what="rgb_map unfused vs fused")
+    close(loss_u, loss_f, atol=1e-6, rtol=1e-5, what="loss unfused vs fused")
+    # same kernels' arithmetic split at `raw`: per tensor within 1e-6 of its largest entry
+    worst = 0.0
+    for key, (off, cnt) in net.layout.items():
+        a, b = g_unf[off:off + cnt], g_fused[off:off + cnt]
+        if float(b.abs().max()) > 0:
+            worst = max(worst, _rel_to_max(a, b))
+            assert _rel_to_max(a, b) <= 1e-6, (key, _rel_to_max(a, b))
+        else:
+            assert not a.any(), key
+    # (c) ... and the oracle's, on the masks of the forward that was just differentiated
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, _, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, white_bkgd=wb)
+    close(loss_u, scal["loss"], atol=1e-5, rtol=1e-4, what="loss vs oracle")
+    g = g_unf.cpu()
+    for key, (off, cnt) in net.layout.items():
+        if grads[key] is not None:
+            grad_close_tight(g[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), f"grad {key} [{n_flips} masks differ, fused-vs-unfused {worst:.1e}]")
+
+
+def test_chunked_custom_query_fn_trains_through_the_one_stash():
+    """A caller that chunks the network call itself (its own batchify loop, RUN:47-64): every chunk is a grad-enabled forward that
+    replaces the model's one stash; the nodes whose stash was replaced re-run their forward in the backward - same gradient."""
+    cfg, args, kw_train, model, p, rays, (H, Wd, focal), t_rand, ea, er, target = _problem(64, 3, 24, seed=12)
+    net = model.module
+    embed_fn, _ = cfnerf_amd.get_embedder(10)
+    embeddirs_fn, _ = cfnerf_amd.get_embedder(4)
+
+    def query(chunk):
+        def fn(inputs, viewdirs, network_fn, is_val, is_test):
+            flat = inputs.reshape(-1, 3)
+            dirs = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
+            emb = torch.cat([embed_fn(flat), embeddirs_fn(dirs)], -1)
+            outs, ents = [], []
+            for i in range(0, emb.shape[0], chunk or emb.shape[0]):
+                r, e = network_fn(emb[i:i + (chunk or emb.shape[0])], is_val, is_test)
+                outs.append(r); ents.append(e)
+            return torch.cat(outs, 0).reshape(list(inputs.shape[:-1]) + [3, 4]), torch.cat(ents, 0)
+        return fn
+    common = dict(rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er)
+    got = []
+    for chunk in (None, 1000):
+        net.flat.grad = None
+        rgb, _, _, ex = cfnerf_amd.render(H, Wd, focal, **common, **dict(kw_train, network_query_fn=query(chunk)))
+        # the entropy of a chunked call is the per-chunk mean; weight the data term only so both runs differentiate the same function
+        loss = O.train_loss(rgb, target.to(DEV), ex["loss_entropy"].mean(), 3, 0.0)["loss"]
+        loss.backward()
+        got.append(net.flat.grad.clone())
+    assert float(got[0].abs().max()) > 0
+    for key, (off, cnt) in net.layout.items():
+        a, b = got[1][off:off + cnt], got[0][off:off + cnt]
+        if float(b.abs().max()) > 0:
+            assert _rel_to_max(a, b) <= 2e-5, (key, _rel_to_max(a, b))       # chunk-wise partial sums of dW: order of summation only
+
+
+def test_three_optimizer_steps_through_the_unfused_path_follow_the_fused_path():
+    """create_nerf's own torch.optim.Adam over grad_vars (RUN:339), loss.backward(), optimizer.step() - the reference's loop
+    verbatim - through a custom query fn and through the fused launch: same parameters after three steps."""
+    finals = []
+    for fused in (True, False):
+        torch.manual_seed(4)
+        cfg = O.OracleCfg(netwidth=64, K_samples=4)
+        args, kw_train, _, model, p, optimizer = build_model(cfg, 31)
+        net = model.module
+        rng = np.random.default_rng(8)
+        rays, (H, Wd, focal) = fern_rays(rng, 32)
+        target = torch.tensor(rng.uniform(0, 1, (32, 3)), dtype=torch.float32).to(DEV)
+        q = kw_train["network_query_fn"]
+        kw = kw_train if fused else dict(kw_train, network_query_fn=lambda *a, **k: q(*a, **k))
+        losses = []
+        for step in range(3):
+            t_rand = torch.tensor(rng.uniform(0, 1, (32, 128)), dtype=torch.float32)
+            ea = torch.tensor(rng.standard_normal((4, 1)), dtype=torch.float32)
+            er = torch.tensor(rng.standard_normal((4, 3)), dtype=torch.float32)
+            rgb, _, _, ex = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw)
+            optimizer.zero_grad()
+            loss = _loss_like_the_reference(rgb, ex, target, 4, 0.01)
+            loss.backward()
+            optimizer.step()
+            net.mark_dirty()
+            losses.append(float(loss.detach()))
+        finals.append((net.flat.detach().cpu().clone(), losses))
+    (pf, lf), (pu, lu) = finals
+    np.testing.assert_allclose(lu, lf, rtol=2e-5, atol=2e-6)
+    d = (pf - pu).abs()
+    assert float((d > 1e-6).float().mean()) <= 1e-3 and float(d.max()) <= 3 * 2 * 5e-4 + 1e-6, (float(d.max()), float((d > 1e-6).float().mean()))
