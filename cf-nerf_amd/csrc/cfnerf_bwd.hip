@@ -1123,10 +1123,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // host side
 static const void* bwd_data_fn(int W, bool b16) {
     switch (W) {
-        case 64: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<64, PREC_F32>);
-        case 128: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<128, PREC_F32>);
-        case 256: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<256, PREC_F32>);
-        case 512: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<512, PREC_F32>);
+#define CFN_W_CASE(w) case w: return b16 ? reinterpret_cast<const void*>(bwd_data_kernel<w, PREC_BF16X3>) : reinterpret_cast<const void*>(bwd_data_kernel<w, PREC_F32>);
+        CFN_FOR_EACH_WIDTH(CFN_W_CASE)
+#undef CFN_W_CASE
     }
     return nullptr;
 }

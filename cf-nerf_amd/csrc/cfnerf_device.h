@@ -289,19 +289,22 @@ template <int PREC, int PRE>
 __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, int wave, int n_waves, const float* __restrict__ wp,
                                            const __bf16* __restrict__ wp16, const float* lds_a, int lda) {
     const int lane = lane_id_opaque();
+    // parts of ceil(KC / nparts) chunks: the last part is shorter (or empty: that wave contributes its zeros) when the chunk count
+    // is not a multiple of the part count (netwidth 320 / 448 in the split-bf16 mode).  No early exit: an empty part runs the loops
+    // with a zero trip count (their prefetches read in-range or bounds-checked addresses and feed no MFMA).
     const int ntc = (int)s.nt, nt = wave % ntc, part = wave / ntc, nparts = n_waves / ntc;
     if (PREC == PREC_BF16X3) {
-        const int KC = s.kc16, kcp = KC / nparts, k0 = part * kcp;
+        const int KC = s.kc16, kcp = (KC + nparts - 1) / nparts, k0 = min(part * kcp, KC), cnt = min(kcp, KC - k0);
         const float* a_row = lds_a + (lane & 31) * lda;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
         const int so[1] = {__builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + ((unsigned)nt * KC + k0) * 2048u))};
-        mma_loop16<1, 1, PRE>(acc, wr, lane * 16, so, a_row, 8 * (lane >> 5) + k0 * 16, lda, kcp);
+        mma_loop16<1, 1, PRE>(acc, wr, lane * 16, so, a_row, 8 * (lane >> 5) + k0 * 16, lda, cnt);
     } else {
-        const int KC = s.kc, kcp = KC / nparts, k0 = part * kcp;
+        const int KC = s.kc, kcp = (KC + nparts - 1) / nparts, k0 = min(part * kcp, KC), cnt = min(kcp, KC - k0);
         const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5) + k0 * 8;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7ffffff0, 0x00020000);
         const int so[1] = {__builtin_amdgcn_readfirstlane((int)((s.w_off + ((unsigned)nt * KC + k0) * 256u) * 4u))};
-        mma_loop<1, 1>(acc, wr, lane * 16, so, a_ptr, lda, kcp);
+        mma_loop<1, 1>(acc, wr, lane * 16, so, a_ptr, lda, cnt);
     }
 }
 

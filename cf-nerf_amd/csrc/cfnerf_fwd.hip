@@ -33,9 +33,12 @@ struct FwdCfg {
     static constexpr int LD = act_ld(W);
 };
 
-__host__ __device__ inline size_t fwd_lds_bytes(int W, int ha) {
-    // act[64][LD] | hs[64][ha+4] | rowinfo[65][4] (+pad) | gdir[32] | comp[kMaxK][8] | red[16]
-    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4) + 68 * 4 + 32 + kMaxK * 8 + 16);
+// comp[] holds one 8-float accumulator row per latent sample: sized by the launch's K (rounded up to 16), not by kMaxK, so that
+// two workgroups of the W = 256 kernel keep fitting a CU's 160 KB whatever the limit is
+__host__ __device__ inline int comp_rows(int K) { return (K + 15) / 16 * 16; }
+__host__ __device__ inline size_t fwd_lds_bytes(int W, int ha, int K) {
+    // act[64][LD] | hs[64][ha+4] | rowinfo[65][4] (+pad) | gdir[32] | red[16] | comp[comp_rows(K)][8]
+    return sizeof(float) * ((size_t)kTileM * act_ld(W) + (size_t)kTileM * (ha + 4) + 68 * 4 + 32 + 16 + (size_t)comp_rows(K) * 8);
 }
 
 __device__ __forceinline__ float zlin_f(float t, float nearv, float farv, bool lindisp) {
@@ -101,8 +104,8 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
     float* hs = act + kTileM * LD;
     float* rowinfo = hs + kTileM * HLD;       // [65][4]: x y z zval
     float* gdir = rowinfo + 68 * 4;           // [32]
-    float* comp = gdir + 32;                  // [kMaxK][8]: r g b depth acc T _ _
-    float* red = comp + kMaxK * 8;            // [16]
+    float* red = gdir + 32;                   // [16]
+    float* comp = red + 16;                   // [comp_rows(K)][8]: r g b depth acc T disp _
 
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* __restrict__ wp = A.wp;
@@ -812,7 +815,7 @@ static int max_blocks_per_cu(const void* fn, size_t lds, int threads) {
 template <int W, int MODE, bool TRAIN, int PREC>
 static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
     auto fn = fused_fwd_kernel<W, MODE, TRAIN, PREC>;
-    const size_t lds = fwd_lds_bytes(W, ht.ha_sz);
+    const size_t lds = fwd_lds_bytes(W, ht.ha_sz, a.K);
     const int64_t units = (MODE == 0) ? a.N : (a.P + kTileM - 1) / kTileM;
     int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
     if (grid < 1) grid = 1;
@@ -833,10 +836,9 @@ static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, boo
 
 hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool train, int prec, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
     switch (ht.W) {
-        case 64: return launch_fwd_w<64>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
-        case 128: return launch_fwd_w<128>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
-        case 256: return launch_fwd_w<256>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
-        case 512: return launch_fwd_w<512>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+#define CFN_W_CASE(w) case w: return launch_fwd_w<w>(a, ht, mode, train, prec, n_cu, per_cu, st, grid_out);
+        CFN_FOR_EACH_WIDTH(CFN_W_CASE)
+#undef CFN_W_CASE
     }
     return hipErrorInvalidValue;
 }
@@ -845,7 +847,7 @@ hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool t
 // current): raise the dynamic-LDS limit of every variant and read the occupancy.  Nothing here is process-global.
 template <int W>
 static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
-    const size_t lds = fwd_lds_bytes(W, ha);
+    const size_t lds = fwd_lds_bytes(W, ha, kMaxK);      // the limit; a launch asks for what its K needs
     const void* fns[8] = {
         reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_F32>),
         reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, true, PREC_F32>),
@@ -855,7 +857,7 @@ static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
     for (const void* fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        per_cu = std::min(per_cu, max_blocks_per_cu(fn, lds, FwdCfg<W>::NTHR));
+        per_cu = std::min(per_cu, max_blocks_per_cu(fn, fwd_lds_bytes(W, ha, 16), FwdCfg<W>::NTHR));
     }
 #ifdef CFN_FWD_MAX_PER_CU
     if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
@@ -866,10 +868,9 @@ static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
 
 hipError_t fused_fwd_set_attributes(int W, int ha, int* per_cu_out) {
     switch (W) {
-        case 64: return fwd_attrs_w<64>(ha, per_cu_out);
-        case 128: return fwd_attrs_w<128>(ha, per_cu_out);
-        case 256: return fwd_attrs_w<256>(ha, per_cu_out);
-        case 512: return fwd_attrs_w<512>(ha, per_cu_out);
+#define CFN_W_CASE(w) case w: return fwd_attrs_w<w>(ha, per_cu_out);
+        CFN_FOR_EACH_WIDTH(CFN_W_CASE)
+#undef CFN_W_CASE
     }
     return hipErrorInvalidValue;
 }

@@ -7,6 +7,11 @@
 
 #include "cfnerf_layout.h"
 
+// every netwidth the fused kernels are instantiated for (validate_cfg: multiples of 64 up to 512)
+#ifndef CFN_FOR_EACH_WIDTH      // (development builds narrow the list: -D'CFN_FOR_EACH_WIDTH(X)=X(256)')
+#define CFN_FOR_EACH_WIDTH(X) X(64) X(128) X(192) X(256) X(320) X(384) X(448) X(512)
+#endif
+
 namespace cfnerf {
 
 struct RaysC2W { float m[12]; };

@@ -15,7 +15,7 @@ namespace cfnerf {
 
 constexpr int kMaxDepth = 16;
 constexpr int kTileM = 64;            // rows (points) per workgroup tile
-constexpr int kMaxK = 64;             // latent samples per point supported by the fused kernels
+constexpr int kMaxK = 128;            // latent samples per point supported by the fused kernels (the reference's default K_samples is 64, RUN:631)
 
 struct ParamEntry {
     std::string key;
@@ -44,8 +44,8 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // returns nullptr when valid, else the reason
 inline const char* validate_cfg(const cfnerf_cfg& c) {
     if (c.netdepth < 3 || c.netdepth > kMaxDepth) return "netdepth must be in [3,16] (at netdepth 2 the reference's skip concat feeds feature_linear and crashes)";
-    if (c.netwidth != 64 && c.netwidth != 128 && c.netwidth != 256 && c.netwidth != 512)
-        return "netwidth must be 64, 128, 256 or 512";
+    if (c.netwidth < 64 || c.netwidth > 512 || c.netwidth % 64 != 0)
+        return "netwidth must be a multiple of 64 in [64, 512]";
     if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";
     if (c.multires_views < 1 || enc_ch(c.multires_views) > 32) return "multires_views must be in [1,4]";
     if (c.h_alpha_size != 32 && c.h_alpha_size != 64) return "h_alpha_size must be 32 or 64";

@@ -55,7 +55,7 @@ def allreduce_sum_(grad: torch.Tensor, world: int, group=None, force: bool = Fal
     return grad
 
 
-MAX_K = 64      # kMaxK of the kernels
+MAX_K = 128     # kMaxK of the kernels
 
 
 class Trainer:

@@ -49,7 +49,7 @@ typedef enum cfnerf_status {
 /* The flags of config_parser() that reach the hot path (run_nerf_uncertainty_NF.py:556-719). */
 typedef struct cfnerf_cfg {
     int32_t netdepth;                   /* --netdepth   (8)   skip connection after layer netdepth/2 (RUN:327) */
-    int32_t netwidth;                   /* --netwidth   (256) one of 64, 128, 256, 512 */
+    int32_t netwidth;                   /* --netwidth   (256) a multiple of 64 in [64, 512] */
     int32_t multires;                   /* --multires   (10)  -> 63 input channels (run_nerf_helpers.py:54-69) */
     int32_t multires_views;             /* --multires_views (4) -> 27 channels */
     int32_t h_alpha_size;               /* --h_alpha_size (32) 32 or 64 */

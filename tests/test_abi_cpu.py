@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert L.lib().cfnerf_version() >= 100
 
 
-@pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64)])
+@pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64), (192, 32, 64), (320, 64, 32), (448, 32, 32)])
 def test_flat_layout_is_state_dict_order(W, ha, hr):
     cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
     lay, total = cfnerf_amd.param_layout(cfg)
@@ -45,7 +45,7 @@ def test_flat_layout_is_state_dict_order(W, ha, hr):
 def test_unsupported_configs_are_rejected_loudly():
     lib = L.lib()
     for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 3), L.Cfg(8, 256, 11, 4, 32, 64, 4),
-                L.Cfg(2, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4)):
+                L.Cfg(2, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4), L.Cfg(8, 576, 10, 4, 32, 64, 4), L.Cfg(8, 0, 10, 4, 32, 64, 4)):
         assert lib.cfnerf_param_count(C.byref(bad)) < 0
         assert lib.cfnerf_last_error() != b""
 
@@ -62,7 +62,7 @@ def _decode(packed, w_off, kc, nt):
     return M
 
 
-@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 32)])
+@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 32), (192, 32, 64), (384, 64, 64)])
 def test_packed_operands_decode_to_the_weights(W, ha, hr):
     lib = C.CDLL(L.LIB_PATH)
     cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
@@ -161,7 +161,8 @@ def test_seeded_construction_replays_the_reference_rng_stream(golden, tag):
     assert n_checked == n_params
 
 
-@pytest.mark.parametrize("W,D,ha,hr", [(256, 8, 32, 64), (64, 8, 32, 64), (128, 6, 32, 32), (512, 8, 64, 64), (256, 3, 64, 32), (512, 16, 32, 64)])
+@pytest.mark.parametrize("W,D,ha,hr", [(256, 8, 32, 64), (64, 8, 32, 64), (128, 6, 32, 32), (512, 8, 64, 64), (256, 3, 64, 32), (512, 16, 32, 64), (192, 8, 32, 64), (320, 8, 32, 64),
+                                       (384, 6, 64, 32), (448, 8, 32, 64)])
 def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
     """Host logic of the backward: the big / small dW tiles (wave arrangement GN x GK of the small kernel included)
     must write every live weight element exactly once per split slot and never touch biases or dead tensors."""
@@ -207,7 +208,8 @@ def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
 
 
 @pytest.mark.parametrize("W,D,P,n_cu", [(256, 8, 131072, 256), (128, 8, 5120, 256), (256, 8, 1024, 256), (512, 8, 65536, 256), (64, 4, 640, 256),
-                                        (256, 8, 524288, 256), (128, 6, 33 * 130, 256), (256, 8, 131072, 64)])
+                                        (256, 8, 524288, 256), (128, 6, 33 * 130, 256), (256, 8, 131072, 64), (192, 8, 131072, 256), (320, 8, 65536, 256),
+                                        (448, 8, 4096, 256)])
 def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     """Host logic of the backward: for every tile the blocks' point ranges tile [0, P) exactly once, their split slots
     are 0 .. nsplit-1, every tensor is reduced over at least the slots its tiles write, and the big launch (2 x 4 and

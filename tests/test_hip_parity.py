@@ -45,7 +45,9 @@ def test_model_forward_vs_reference_golden(golden, tag):
     close(ent.reshape(-1)[0], g["loss_entropy"], what="loss_entropy")
 
 
-@pytest.mark.parametrize("W,K,P", [(256, 4, 1000), (256, 32, 129), (512, 8, 200), (128, 3, 64), (64, 1, 1)])
+@pytest.mark.parametrize("W,K,P", [(256, 4, 1000), (256, 32, 129), (512, 8, 200), (128, 3, 64), (64, 1, 1),
+                                   # every netwidth that is a multiple of 64 (RUN:584 takes any), K up to 128 (RUN:631 defaults to 64)
+                                   (192, 4, 150), (320, 5, 130), (384, 3, 70), (448, 2, 65), (256, 128, 70), (64, 100, 33)])
 def test_model_forward_vs_oracle(W, K, P):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
     _, kw, _, model, p, _ = build_model(cfg, 100 + W + K)
@@ -199,7 +201,9 @@ def test_get_rays_and_ndc_rays_helpers_vs_reference_golden(golden):
         cfnerf_amd.ndc_rays(H, W, focal, 1., ro.cpu(), rd.cpu())
 
 
-@pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True)])
+@pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True),
+                                       (192, 3, 20, True), (320, 4, 12, False), (384, 2, 10, True), (448, 3, 9, True), (128, 128, 5, True),
+                                       (256, 96, 4, False)])
 def test_render_vs_oracle(W, K, N, ndc):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
     _, kw_train, kw_test, model, p, _ = build_model(cfg, 300 + W + K, no_ndc=not ndc)
@@ -368,13 +372,17 @@ def test_generic_depth_k_limit_single_ray_long_tables(D, W, K, N, S):
 def test_k_above_the_limit_and_bad_widths_are_rejected():
     import argparse
     from util_hip import make_args
-    cfg = O.OracleCfg(netwidth=64, K_samples=65)
+    cfg = O.OracleCfg(netwidth=64, K_samples=129)
     args = make_args(cfg)
     kw, _, _, _, _ = cfnerf_amd.create_nerf(args)
     with pytest.raises(RuntimeError, match="K_samples"):
         cfnerf_amd.render_rays(torch.zeros(2, 11, device=DEV) + 0.5, **{k: v for k, v in kw.items() if k != "use_viewdirs"})
     with pytest.raises(RuntimeError, match="netwidth"):
         cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=96)))
+    with pytest.raises(RuntimeError, match="netwidth"):
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=576)))
+    with pytest.raises(RuntimeError, match="h_alpha_size"):
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=64, h_alpha_size=96)))
 
 
 # ---------------------------------------------------------------- standalone boundary kernels
