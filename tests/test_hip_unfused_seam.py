@@ -187,7 +187,7 @@ def test_training_through_a_custom_query_fn_gives_the_fused_gradients_and_the_or
     g = g_unf.cpu()
     for key, (off, cnt) in net.layout.items():
         if grads[key] is not None:
-            grad_close_tight(g[off:off + cnt].reshape(grads[key].shape), grads[key].numpy(), f"grad {key} [{n_flips} masks differ, fused-vs-unfused {worst:.1e}]")
+            grad_close_tight(g[off:off + cnt].reshape(grads[key].shape), grads[key], f"grad {key} [{n_flips} masks differ, fused-vs-unfused {worst:.1e}]")
 
 
 def test_chunked_custom_query_fn_trains_through_the_one_stash():

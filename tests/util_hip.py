@@ -1,5 +1,6 @@
 """Shared helpers for the -m gpu parity tests (HIP path through the C ABI vs the CPU oracle)."""
 import argparse
+import os
 
 import numpy as np
 import torch
@@ -97,9 +98,12 @@ def hip_relu_masks(net, P):
 
 
 def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=False, white_bkgd=False,
-                                   max_flip_frac=2e-4, t_vals=None):
+                                   max_flip_frac=2e-4, t_vals=None, f64=True):
     """(scalars, grads, ret, n_flips): the oracle's train step differentiated on the ReLU masks of the HIP forward that
-    was just run on the same inputs, after checking that those masks differ from the oracle's own only by rounding."""
+    was just run on the same inputs, after checking that those masks differ from the oracle's own only by rounding.
+    `f64` (default): the differentiation runs in float64, so the reference gradient carries no fp32 noise of its own (the
+    transmittance adjoint divides by ~1e-10 factors: an fp32 oracle is as noisy there as the kernels) and the per-tensor
+    bounds of grad_close_tight measure the HIP path alone."""
     S = 128 if t_vals is None else int(t_vals.shape[0])
     P = packed.shape[0] * S
     acts, masks = hip_relu_masks(net, P)
@@ -118,13 +122,71 @@ def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 
         n_flips += int(flip.sum())
         n_units += flip.numel()
     assert n_flips <= max(2, max_flip_frac * n_units), f"{n_flips} of {n_units} ReLU masks differ"
+    if not f64:
+        with O.relu_override(masks=masks):
+            scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
+        return scal, grads, ret, n_flips
+    d = lambda t: None if t is None else t.double()
     with O.relu_override(masks=masks):
-        scal, grads, ret = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
+        # train_step of the oracle in fp64, written out so that the backward can be run twice (see below)
+        q = {k: d(v).clone().requires_grad_(True) for k, v in p.items()}
+        ret = O.render_rays(q, d(packed), cfg, d(ea), d(er), True, d(t_rand), lindisp, white_bkgd, t_vals=d(t_vals))
+        L = O.train_loss(ret["rgb_map"], d(target), ret["loss_entropy"], cfg.K_samples, beta1)
+        keys = [k for k in q]
+        (G,) = torch.autograd.grad(L["loss"], ret["rgb_map"], retain_graph=True)
+        outs, cots = [ret["rgb_map"]], [G]
+        if beta1:
+            outs.append(ret["loss_entropy"]); cots.append(torch.tensor(float(beta1), dtype=torch.float64))
+        gl = torch.autograd.grad(outs, [q[k] for k in keys], cots, retain_graph=True, allow_unused=True)
+        grads = dict(zip(keys, gl))
+        scal = {k: float(v.detach()) for k, v in L.items()}
+        scal["loss_entropy"] = float(ret["loss_entropy"].detach())
+        ret = {k: v.detach() for k, v in ret.items() if v is not None}
+        # Calibration of the bound, per tensor and per case.  (1) the SAME differentiation in fp32: what a straightforward fp32
+        # implementation of this math delivers on THESE inputs.  (2) the conditioning of the case: a correct fp32 forward returns
+        # rgb_map within ~5e-7, which moves the loss gradient d loss / d rgb_map by ~2e-6 of its largest entry (measured: HIP 1.7e-6,
+        # fp32 oracle 1.0e-6) - for K = 2..3 the KDE bandwidth is tiny and the loss is steep; how far THAT moves each parameter
+        # gradient is measured by a second fp64 backward with the cotangent perturbed by 2e-6 max|G|.  The alpha path (transmittance
+        # adjoint: differences of nearly equal terms) amplifies it up to 100x on random sample tables; measured with
+        # tests/tools/alpha_grad_diag.py: the fused backward fed the EXACT fp64 loss gradient at the HIP forward's rgb_map shows the
+        # same deviation, i.e. it is the true gradient at a forward point 5e-7 away, not an error of the backward.
+        gen = torch.Generator().manual_seed(0)
+        Gp = G + 2e-6 * float(G.abs().max()) * (torch.rand(G.shape, generator=gen, dtype=torch.float64) * 2 - 1)
+        gp = torch.autograd.grad(outs, [q[k] for k in keys], [Gp] + cots[1:], allow_unused=True)
+        _, g32, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
+        for k, g, g2 in zip(keys, gl, gp):
+            if g is not None:
+                m = g.abs().max().clamp_min(1e-300)
+                g.fp32_noise = max(float((g32[k].double() - g).abs().max() / m), float((g2 - g).abs().max() / m))
     return scal, grads, ret, n_flips
 
 
-def grad_close_tight(g, ref, what, tol=G_TIGHT):
+G_FLOOR, G_CAP, G_NOISE_X = 2e-5, 1e-3, 10.0
+
+
+def grad_close_tight(g, ref, what, tol=None):
+    """Every entry of a gradient tensor within `tol` of the tensor's largest entry (+ 1e-4 relative), and the tensor's RMS error
+    within `tol` of its RMS.  `ref`: numpy, or a torch tensor from oracle_train_step_on_hip_masks - those carry `fp32_noise`, the
+    error of the fp32 CPU oracle against the fp64 one on the same inputs, and the bound is G_NOISE_X times that, clipped to
+    [G_FLOOR, G_CAP] (measured over the suite: HIP error / fp32-oracle error stays below G_NOISE_X; typical errors are 3e-7 .. 6e-6,
+    the floor sits ~10x above them).  Without it (fixtures of the real reference, themselves fp32): the fixed G_TIGHT."""
+    noise = getattr(ref, "fp32_noise", None)
+    if torch.is_tensor(ref):
+        ref = ref.detach().cpu().double().numpy()
     ref = np.asarray(ref, dtype=np.float64)
     g = g.detach().cpu().double().numpy() if torch.is_tensor(g) else np.asarray(g, dtype=np.float64)
+    if tol is None:
+        tol = G_TIGHT if noise is None else min(max(G_NOISE_X * noise, G_FLOOR), G_CAP)
+    tol_rms = tol if noise is None else min(max(0.5 * G_NOISE_X * noise, G_FLOOR), G_CAP)
     scale = max(float(np.abs(ref).max()), 1e-12)
-    close(g, ref, atol=tol * scale, rtol=2e-3, what=what)
+    rms_rel = float(np.sqrt(((g - ref) ** 2).sum() / max(float((ref ** 2).sum()), 1e-300)))
+    stats = os.environ.get("CFNERF_GRAD_STATS")          # development aid: log the measured error of every comparison
+    if stats:
+        import json
+        with open(stats, "a") as f:
+            f.write(json.dumps({"what": what, "rel_to_max": float(np.abs(g - ref).max() / scale), "scale": scale, "n": int(ref.size),
+                                "rms_rel": rms_rel, "noise": noise, "tol": tol}) + "\n")
+    if stats and os.environ.get("CFNERF_GRAD_STATS_ONLY") == "1":
+        return                                           # survey mode: record every comparison, judge none
+    close(g, ref, atol=tol * scale, rtol=1e-4, what=what)
+    assert rms_rel <= tol_rms, f"{what}: RMS error {rms_rel:.2e} of the tensor's RMS exceeds {tol_rms:.1e}"
