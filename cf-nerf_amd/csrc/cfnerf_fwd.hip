@@ -208,8 +208,26 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             // instead the tile is parked as 16 KB of row-major fp32 - in the activation stash when there is one (the backward
             // wants it there anyway), else in this workgroup's slot of a small L2-resident scratch - and fetched back with
             // four 16-byte loads per thread.
-            float* enc_park = (MODE == 0) ? (A.st_enc != nullptr ? A.st_enc + p0 * 64 : A.enc_scratch + (size_t)blockIdx.x * (kTileM * 64)) : nullptr;
-            if (MODE == 0 || A.st_enc != nullptr) {
+            // The EVAL variants of the exact-fp32 path keep it in REGISTERS instead (16 per thread with 4 waves, 8 with 8): the scratch
+            // slot was rewritten every tile and every one of those writes went through L2 to memory - 33 MB of WRITE_SIZE per C2
+            // launch against 82 KB of outputs (profiles/r02_traffic.json).  (The split-bf16 eval kernel has no registers to spare and the
+            // train variants want the tile in the stash anyway: they park it in memory as before.)
+#ifdef CFN_PARK_MEM      // (A/B builds: the round-2 scheme)
+            constexpr bool kParkRegs = false;
+#else
+            constexpr bool kParkRegs = MODE == 0 && !TRAIN && PREC == PREC_F32;
+#endif
+            constexpr int kParkN = kTileM * 16 / kThr;
+            f32x4 park[kParkRegs ? kParkN : 1];
+            float* enc_park = (MODE == 0 && !kParkRegs) ? (A.st_enc != nullptr ? A.st_enc + p0 * 64 : A.enc_scratch + (size_t)blockIdx.x * (kTileM * 64)) : nullptr;
+            if (kParkRegs) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < kParkN; ++i) {
+                    const int idx = tid + i * kThr, row = idx >> 4, q = idx & 15;
+                    park[i] = *reinterpret_cast<const f32x4*>(act + row * LD + 4 * q);
+                }
+            } else if (MODE == 0 || A.st_enc != nullptr) {
                 __syncthreads();
                 float* dst = (MODE == 0) ? enc_park : A.st_enc + p0 * 64;
                 for (int idx = tid; idx < kTileM * 16; idx += kThr) {
@@ -237,7 +255,13 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == T.skip) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
-                    if (MODE == 0) {                 // act[:, 0:64) <- gamma(p) again, from where the tile was parked
+                    if (kParkRegs) {                 // act[:, 0:64) <- gamma(p) again, from the registers it was kept in
+#pragma unroll
+                        for (int i = 0; i < kParkN; ++i) {
+                            const int idx = tid + i * kThr, row = idx >> 4, q = idx & 15;
+                            *reinterpret_cast<f32x4*>(act + row * LD + 4 * q) = park[i];
+                        }
+                    } else if (MODE == 0) {          // ... or from where the tile was parked
                         for (int idx = tid; idx < kTileM * 16; idx += kThr) {
                             const int row = idx >> 4, q = idx & 15;
                             f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;           // rows past a ragged tile: finite filler
