@@ -346,6 +346,45 @@ __device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t r, int voff_by
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff_bytes, soff_bytes, /*nt*/ 2);
 }
 
+// Copy-out of a tile the epilogue has just written to LDS (row-major, stride ld) to its row-major HBM slab, as 16-byte pieces:
+// 64 lanes x 16 B = 1 KB contiguous per instruction (one whole row of a 256-wide stream).  Storing the fragment elements from the
+// accumulator registers instead costs one buffer_store_dword per element - 256 B per instruction in two 128-B pieces - and the
+// texture-address unit, not HBM, was what the 1.5 GB of activation stash cost the train forward (~65 us per launch):
+// four times fewer vector-memory instructions move the same bytes.  No VALU work: ds_read_b128 + buffer_store_dwordx4, issued
+// right after the barrier that follows the epilogue, in front of the next MFMA block (which only READS the tile; whatever WRITES the
+// tile next sits behind another barrier, which a wave only reaches after its own copy-out reads have returned).  Rows past a
+// ragged tile fall outside the descriptor.  fp32 tiles only (the split-bf16 tiles hold hi / lo planes).  Used by the train forward
+// (-27 us at C2, -25 us at W = 512).  Backward-data keeps its element stores: the same scheme there measured -4 us at W = 256 and
+// +18 us at W = 512, and its last copy-out of a tile would need one more barrier in front of the next tile's first LDS write.
+#ifdef CFN_STASH_FROM_REGS      // (A/B builds: the round-2 scheme, fragment elements as dwords)
+constexpr bool kStashFromLds = false;
+#else
+constexpr bool kStashFromLds = true;
+#endif
+template <int WIDTH, int NTHR>
+__device__ __forceinline__ void stash_rows(const float* lds, int ld, float* __restrict__ gdst, int rows_valid) {
+    constexpr int QPR = WIDTH / 4, TOTAL = kTileM * QPR;              // 16-byte pieces per row / per tile
+    static_assert(TOTAL % NTHR == 0, "tile pieces must divide over the workgroup");
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, rows_valid, WIDTH);
+    const int tid = threadIdx.x;
+    // batches of 4 pieces (16 registers in flight, not 64: the accumulators are dead here but the kernel has no registers to spare)
+    constexpr int PER = TOTAL / NTHR, B = PER % 4 == 0 ? 4 : (PER % 2 == 0 ? 2 : 1);
+#pragma unroll 1
+    for (int b = 0; b < PER / B; ++b) {
+        u32x4 v[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int idx = tid + (b * B + i) * NTHR, row = idx / QPR, q = idx - row * QPR;
+            v[i] = *reinterpret_cast<const u32x4*>(lds + row * ld + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int idx = tid + (b * B + i) * NTHR, row = idx / QPR, q = idx - row * QPR;
+            __builtin_amdgcn_raw_buffer_store_b128(v[i], sink, (row * WIDTH + 4 * q) * 4, 0, /*nt*/ 2);
+        }
+    }
+}
+
 // ReLU mask of a lane's 32-row output fragment as ONE word, element e = i * 16 + r at bit 31 - e: built with one
 // v_sub + one v_alignbit per element (the sign bit of 0 - bits(v) is set iff v > 0 for a post-ReLU v), read back in
 // the backward with one v_bfe_i32 (sign-extended 1-bit field = all-ones / zero mask).

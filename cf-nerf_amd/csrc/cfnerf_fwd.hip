@@ -281,9 +281,11 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.trunk[l], wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, T.trunk[l], wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
+                if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
                 CFN_MARK();                          // epilogue + barrier done
             }
 
@@ -321,9 +323,11 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                     }
                 }
                 __syncthreads();
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN, true>(accF, T.ft, wave, kWv, wp, act, LD, 0,
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, T.ft, wave, kWv, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
+                if (kRows && A.st_feat != nullptr) stash_rows<W, kThr>(act, LD, A.st_feat + p0 * W, rows_valid);
             }
             CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
@@ -346,9 +350,11 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 mma_any<C::NTV, PREC, 2>(acc, T.vd, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN, true>(acc, T.vf, wave, kWv, wp, act, LD, 0,
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, T.vf, wave, kWv, wp, act, LD, 0,
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
+                if (kRows && A.st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, A.st_v + p0 * (W / 2), rows_valid);
             }
             CFN_MARK();                              // views done
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
