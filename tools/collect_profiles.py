@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Assemble profiles/rNN_* from the output of tools/profile_round.sh (gpurun_out/i_*):
    kernel-stats CSVs as rocprofv3 wrote them, one PMC summary text, and rNN_traffic.json (what bench.py's roofline.traffic reads).
-   usage: python tools/collect_profiles.py r02"""
+   usage: python tools/collect_profiles.py r03"""
 import csv
 import json
 import os
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 
 for n, out in (("train", "train"), ("eval", "eval"), ("train_b16", "train_bf16x3"), ("w512", "w512_train"), ("c4", "c4_train"), ("c3", "c3_train")):
@@ -67,12 +67,13 @@ for key, suffix, kern in (("C2:train", "", "fused_fwd_kernel<256, 0, true, 0>"),
         traffic[key] = e
 with open(os.path.join(P, f"{tag}_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
-for n in ("bench_r02_c2.json", "bench_r02_eval.json"):
-    src = os.path.join(G, n)
-    if os.path.exists(src):
-        with open(src) as f:
-            lines = [l for l in f.read().strip().splitlines() if l.startswith("{")]
-        if lines:
-            with open(os.path.join(P, n.replace("bench_r02", f"{tag}_bench")), "w") as o:
-                o.write(json.dumps(json.loads(lines[-1]), indent=1) + "\n")
+# bench lines of the round: gpurun_out/bench_<tag>_<name>.json (written by tools/bench_round.sh) -> profiles/<tag>_bench_<name>.json
+import glob
+for src in sorted(glob.glob(os.path.join(G, f"bench_{tag}_*.json"))):
+    with open(src) as f:
+        lines = [l for l in f.read().strip().splitlines() if l.startswith("{")]
+    if lines:
+        name = os.path.basename(src)[len(f"bench_{tag}_"):]
+        with open(os.path.join(P, f"{tag}_bench_{name}"), "w") as o:
+            o.write(json.dumps(json.loads(lines[-1])) + "\n")
 print("wrote", sorted(x for x in os.listdir(P) if x.startswith(tag)))
