@@ -48,6 +48,7 @@ _SIGS = {
     "cfnerf_stream_wait_grad_early": (C.c_int, [_P, _P]),
     "cfnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "cfnerf_model_set_precision": (C.c_int, [_P, C.c_int]),
+    "cfnerf_model_set_flow_math": (C.c_int, [_P, C.c_int]),
     "cfnerf_model_workspace_bytes": (C.c_int64, [_P]),
     "cfnerf_timing_enable": (C.c_int, [_P, C.c_int]),
     "cfnerf_timing_last_ms": (C.c_float, [_P, C.c_int]),

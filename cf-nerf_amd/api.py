@@ -382,6 +382,12 @@ class NeRF_Flows(nn.Module):
         L.check(L.lib().cfnerf_model_set_precision(self._h, code), "cfnerf_model_set_precision")
         self.precision = mode
 
+    def set_flow_math(self, mode: str):
+        """Arithmetic of the flows + composite inside the fused kernels: 'libm' (correctly rounded routines), 'fast' (hardware
+        exp2 / log2 / rcp forms, same parity bounds) or 'auto' (default: libm below 16 latent samples, fast from 16 on)."""
+        L.check(L.lib().cfnerf_model_set_flow_math(self._h, {"auto": 0, "libm": 1, "fast": 2}[mode]), "cfnerf_model_set_flow_math")
+        self.flow_math = mode
+
     def eval_eps(self):
         """[K,4] eval latents: the fixed buffers with the LAST sample zeroed (MOD:199,205)."""
         # the device copy is rebuilt only when the (plain-attribute) latents were replaced or edited in place

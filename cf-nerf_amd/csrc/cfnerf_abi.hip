@@ -226,6 +226,10 @@ int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_
     return CFNERF_OK;
 }
 
+static int flow_math_bits(const cfnerf_model* m) {
+    return m->flow_math == 0 ? 0 : (CFNERF_F_FLOW_MATH_SET | (m->flow_math == 2 ? CFNERF_F_FLOW_MATH_FAST : 0));
+}
+
 static int check_common(cfnerf_model* m, int K) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
     if (!m->flat) return fail(CFNERF_E_INVALID, "cfnerf_model_set_params has not been called");
@@ -252,7 +256,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     FwdArgs a{};
     a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.rays = rays; a.t_vals = t_vals; a.t_rand = z_vals_opt ? nullptr : t_rand; a.z_in = z_vals_opt; a.eps = eps;
-    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
+    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = (flags & 0xffff) | flow_math_bits(m);
     a.rgb_map = rgb_map; a.disp = disp_map; a.depth = depth_map;
     a.raw = raw_opt; a.weights = weights_opt; a.pts = pts_opt; a.kstats = kstats_opt;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
@@ -296,7 +300,7 @@ int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, 
     FwdArgs a{};
     a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
     a.rays = rays; a.t_vals = t_vals; a.eps = eps;
-    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = flags;
+    a.N = N; a.S = S; a.K = K; a.P = N * (int64_t)S; a.flags = (flags & 0xffff) | flow_math_bits(m);
     a.kstats = kstats; a.gt = gt_opt; a.sqerr = sqerr_opt; a.enc_scratch = m->d_enc_scratch;
     int grid = 0;
     hipStream_t st = (hipStream_t)s;
@@ -328,7 +332,7 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     hipStream_t st = (hipStream_t)s;
     FwdArgs a{};
     a.wp = m->d_packed; a.wp16 = m->d_packed16; a.flat = m->flat;
-    a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = flags; a.raw = raw;
+    a.eps = eps; a.x = x; a.P = P; a.N = 0; a.S = 1; a.K = K; a.flags = (flags & 0xffff) | flow_math_bits(m); a.raw = raw;
     a.ent_partials = train ? m->d_ent_partials : nullptr;
     if (flags & CFNERF_F_STASH) {            // points-mode stash: the workspace is bound as ONE "ray" of P samples
         char why[256];
@@ -373,6 +377,13 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
         HIPCHK(launch_pack(m->flat, m->d_packed, m->d_packed16, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, nullptr));
         HIPCHK(hipDeviceSynchronize());
     }
+    return CFNERF_OK;
+}
+
+int cfnerf_model_set_flow_math(cfnerf_model* m, int mode) {
+    if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
+    if (mode < 0 || mode > 2) return fail(CFNERF_E_INVALID, "flow math mode must be 0 (auto), 1 (libm) or 2 (hardware transcendentals)");
+    m->flow_math = mode;
     return CFNERF_OK;
 }
 

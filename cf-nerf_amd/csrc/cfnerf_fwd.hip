@@ -10,6 +10,8 @@
 // Reference functions replaced: render_rays RUN:457-553, run_network RUN:67-85, Embedder HLP:21-69,
 // NeRF_Flows.encode/forward MOD:165-291, TriangularSylvesterNeRF MOD:358-416, TriangularSylvester
 // FLW:189-268, raw2outputs RUN:411-454.
+#include <type_traits>
+
 #include "cfnerf_device.h"
 #include "cfnerf_kernels.h"
 
@@ -431,46 +433,54 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                     const float dz = (s == S - 1) ? 1e1f : rowinfo[(row + 1) * 4 + 3] - zval;      // RUN:426-427
                     dist = dz * dnorm;                                                             // RUN:429
                 }
-                for (int k = wave; k < K; k += kWv) {
-                    const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
-                    float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
-                    float a = e[3] * a_std + a_mean;                                               // MOD:200/239
-                    float ldr, lda;
-                    flows_fwd<TRAIN>(th, z, a, ldr, lda);
-                    if (A.raw != nullptr && valid) {
-                        f32x4 o; o[0] = z[0]; o[1] = z[1]; o[2] = z[2]; o[3] = a;
-                        *reinterpret_cast<f32x4*>(A.raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
-                    }
-                    const float sp_a = softplus_f(a);
-                    if (TRAIN && valid) {
-                        ent_a_sum += lda + (a - sp_a);                                                        // MOD:263
-                        ent_r_sum += ldr + (((z[0] + z[1]) + z[2]) - 2.f * ((softplus_f(z[0]) + softplus_f(z[1])) + softplus_f(z[2])));  // MOD:278
-                    }
-                    if (MODE == 0) {
-                        const float alpha = valid ? 1.f - expf(-sp_a * dist) : 0.f;                // RUN:424,442
-                        const float xk = (1.f - alpha) + 1e-10f;                                   // RUN:443
-                        const float incl = wave_scan_mul(xk);
-                        float excl = __shfl_up(incl, 1, 64);
-                        if (lane == 0) excl = 1.f;
-                        float* cp = comp + k * 8;
-                        const float Tcar = cp[5];
-                        const float wgt = alpha * (Tcar * excl);
-                        if (A.weights != nullptr && valid) A.weights[(p0 + row) * (int64_t)K + k] = wgt;
-                        if (A.st_at != nullptr && valid) {
-                            f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
-                            *reinterpret_cast<f32x2*>(A.st_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
+                // the K flows + the composite of this tile in one of two arithmetic flavours (see Num<FAST> in cfnerf_device.h)
+                auto flow_phase = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    using M = Num<FAST>;
+                    for (int k = wave; k < K; k += kWv) {
+                        const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+                        float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
+                        float a = e[3] * a_std + a_mean;                                               // MOD:200/239
+                        float ldr, lda;
+                        flows_fwd<TRAIN, FAST>(th, z, a, ldr, lda);
+                        if (A.raw != nullptr && valid) {
+                            f32x4 o; o[0] = z[0]; o[1] = z[1]; o[2] = z[2]; o[3] = a;
+                            *reinterpret_cast<f32x4*>(A.raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
                         }
-                        const float s0 = wave_sum(wgt * sigmoid_f(z[0]));                          // RUN:431,444
-                        const float s1 = wave_sum(wgt * sigmoid_f(z[1]));
-                        const float s2 = wave_sum(wgt * sigmoid_f(z[2]));
-                        const float sd = wave_sum(wgt * zval);                                     // RUN:447
-                        const float sa = wave_sum(wgt);                                            // RUN:449
-                        const float tot = __shfl(incl, 63, 64);
-                        if (lane == 0) {
-                            cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar * tot;
+                        const float sp_a = M::softplus(a);
+                        if (TRAIN && valid) {
+                            ent_a_sum += lda + (a - sp_a);                                                        // MOD:263
+                            ent_r_sum += ldr + (((z[0] + z[1]) + z[2]) - 2.f * ((M::softplus(z[0]) + M::softplus(z[1])) + M::softplus(z[2])));  // MOD:278
+                        }
+                        if (MODE == 0) {
+                            const float alpha = valid ? 1.f - M::exp(-sp_a * dist) : 0.f;                // RUN:424,442
+                            const float xk = (1.f - alpha) + 1e-10f;                                   // RUN:443
+                            const float incl = wave_scan_mul(xk);
+                            float excl = __shfl_up(incl, 1, 64);
+                            if (lane == 0) excl = 1.f;
+                            float* cp = comp + k * 8;
+                            const float Tcar = cp[5];
+                            const float wgt = alpha * (Tcar * excl);
+                            if (A.weights != nullptr && valid) A.weights[(p0 + row) * (int64_t)K + k] = wgt;
+                            if (A.st_at != nullptr && valid) {
+                                f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
+                                *reinterpret_cast<f32x2*>(A.st_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
+                            }
+                            const float s0 = wave_sum(wgt * M::sigmoid(z[0]));                          // RUN:431,444
+                            const float s1 = wave_sum(wgt * M::sigmoid(z[1]));
+                            const float s2 = wave_sum(wgt * M::sigmoid(z[2]));
+                            const float sd = wave_sum(wgt * zval);                                     // RUN:447
+                            const float sa = wave_sum(wgt);                                            // RUN:449
+                            const float tot = __shfl(incl, 63, 64);
+                            if (lane == 0) {
+                                cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar * tot;
+                            }
                         }
                     }
-                }
+                };
+                const bool fast = (A.flags & CFNERF_F_FLOW_MATH_SET) ? (A.flags & CFNERF_F_FLOW_MATH_FAST) != 0 : K >= kFastFlowsK;     // wave-uniform
+                if (fast) flow_phase(std::true_type{});
+                else flow_phase(std::false_type{});
             }
             __syncthreads();
             CFN_MARK();                              // flows + composite done

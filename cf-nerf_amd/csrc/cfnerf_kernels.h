@@ -14,6 +14,10 @@
 
 namespace cfnerf {
 
+// internal bits of FwdArgs::flags (above the public CFNERF_F_*): the arithmetic flavour of the flow phase forced by
+// cfnerf_model_set_flow_math (neither set: libm below kFastFlowsK latents, hardware transcendentals from there on)
+constexpr int CFNERF_F_FLOW_MATH_SET = 1 << 16, CFNERF_F_FLOW_MATH_FAST = 1 << 17;
+
 struct RaysC2W { float m[12]; };
 
 struct FwdArgs {

@@ -117,6 +117,7 @@ struct cfnerf_model {
     float* d_packed = nullptr;
     void* d_packed16 = nullptr;           // split-bf16 operand copies (bf16x3 mode)
     int precision = 0;                    // 0 = fp32 MFMA (default), 1 = bf16x3 split MFMA in the forward
+    int flow_math = 0;                    // 0 = auto (libm below 16 latents, hardware transcendentals from there), 1 = libm, 2 = hardware
     cfnerf::PackDesc* d_descs = nullptr;
     const float* flat = nullptr;          // caller-owned flat parameter buffer (last set_params)
     float* d_ent_partials = nullptr; int ent_cap = 0;

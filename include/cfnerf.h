@@ -235,6 +235,14 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
  * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).                */
 int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 
+/* Arithmetic of the flow phase of the fused kernels (the K conditional Sylvester flows, MOD:401-413 / FLW:225-268, the activations
+ * and the composite, RUN:424-449, of every (point, latent sample)).  1: libm throughout (correctly rounded tanhf / logf / expf /
+ * log1pf, IEEE division) - ~1300 vector instructions per (point, latent).  2: the same functions on the hardware transcendentals
+ * (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each; tanh = 1 - 2 / (1 + e^2x)) - ~250 instructions; held to the same parity bounds
+ * by the tests.  0 (default): 1 below 16 latent samples (the reference's plumbing and headline configurations stay on libm bit
+ * for bit), 2 from 16 on, where the flow phase grows from 5 % (K = 16) to 20 % (K = 64, the reference's default) of the launch.   */
+int cfnerf_model_set_flow_math(cfnerf_model* m, int mode);
+
 /* bytes currently held by the model: packed weights + the bound workspace, whoever owns it (diagnostics) */
 int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
 
