@@ -122,6 +122,58 @@ def test_render_batch_vs_reference_golden(golden, tag):
     close(disp_e, g["disp_map_eval"], atol=ATOL_DISP, rtol=1e-3, what="disp_map_eval")
 
 
+@pytest.mark.parametrize("tag", ["w64_nondc_lindisp_wb", "w256_ndc"])
+def test_render_batch_with_hardware_flow_math_vs_reference_golden(golden, tag):
+    """cfnerf_model_set_flow_math: the K flows + composite on the hardware transcendentals (what the fused kernels take by themselves
+    from 16 latents on), FORCED here on the K = 4 fixtures of the real reference: same outputs within the same bounds, not the same bits."""
+    g = golden(f"g57_render_{tag}")
+    cfg = cfg_from(g)
+    over = dict(no_ndc=not bool(g["ndc"]), lindisp=bool(g["lindisp"]), white_bkgd=bool(g["white_bkgd"]))
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]), **over)
+    net = model.module
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    kw = dict(rays=T(g["rays"]).to(DEV), near=float(g["near"]), far=float(g["far"]), t_rand=T(g["t_rand"]), eps_alpha=T(g["eps_alpha"]),
+              eps_rgb=T(g["eps_rgb"]))
+    out = {}
+    for mode in ("libm", "fast", "auto"):
+        net.set_flow_math(mode)
+        with torch.no_grad():
+            out[mode] = cfnerf_amd.render(H, W, focal, **kw, **kw_train)
+    rgbs, disp, depth, extras = out["fast"]
+    close(extras["raw"], g["raw"], what="raw")
+    close(rgbs, g["rgb_map"], what="rgb_map")
+    close(depth, g["depth_map"], what="depth_map")
+    close(disp, g["disp_map"], atol=ATOL_DISP, rtol=1e-3, what="disp_map")
+    close(extras["loss_entropy"].mean(), g["loss_entropy"], what="loss_entropy")
+    assert not torch.equal(out["fast"][3]["raw"], out["libm"][3]["raw"])                  # a different arithmetic path ...
+    assert torch.equal(out["auto"][3]["raw"], out["libm"][3]["raw"]) and torch.equal(out["auto"][0], out["libm"][0])    # ... that K = 4 does not take by default
+    with pytest.raises(KeyError):
+        net.set_flow_math("fastest")
+
+
+def test_flow_math_default_switches_at_16_latents():
+    """auto = libm below 16 latent samples, hardware forms from 16 on; both against the oracle at K = 32 (the authors' recipe)"""
+    cfg = O.OracleCfg(netwidth=128, K_samples=32)
+    _, kw_train, _, model, p, _ = build_model(cfg, 66)
+    net = model.module
+    rng = np.random.default_rng(2)
+    rays, (H, Wd, focal) = fern_rays(rng, 12)
+    t_rand = torch.tensor(rng.uniform(0, 1, (12, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((32, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((32, 3)), dtype=torch.float32)
+    r = O.render(p, H, Wd, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=t_rand)
+    out = {}
+    for mode in ("auto", "libm", "fast"):
+        net.set_flow_math(mode)
+        with torch.no_grad():
+            out[mode] = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+        close(out[mode][3]["raw"], r["raw"], what=f"raw [{mode}]")
+        close(out[mode][0], r["rgb_map"], what=f"rgb_map [{mode}]")
+        close(out[mode][2], r["depth_map"], what=f"depth_map [{mode}]")
+        close(out[mode][3]["loss_entropy"].mean(), r["loss_entropy"], what=f"entropy [{mode}]")
+    assert torch.equal(out["auto"][0], out["fast"][0]) and not torch.equal(out["auto"][0], out["libm"][0])
+
+
 def test_render_config1_k1_vs_reference_golden(golden):
     """G14 = BASELINE config 1 through render() (RUN:103-170): K = 1 latent sample, N_rand = 256 fern-shaped rays, default
     width, forward only (the reference's K = 1 train loss is NaN) - train-mode and eval-mode render."""
