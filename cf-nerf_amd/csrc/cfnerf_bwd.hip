@@ -576,7 +576,20 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
             dbp[A.db_theta + tid] += s;
         }
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
-        {
+        if (T.bt_fr.nt > 2 || T.bt_fa.nt > 2) {
+            // h sizes of 96 / 128 (3 - 4 n-tiles per head): every wave takes n-tile `wave` of BOTH heads, one after the other
+            f32x16 accR[2][1], accA[2][1];
+            EpiPre<1> eR, eA;
+            acc_zero(accR); acc_zero(accA);
+            epi_prefetch<1>(eR, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
+            epi_prefetch<1>(eA, T.bt_fa.nt, wave, kWaves, nullptr, dbp + A.db_ha);
+            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accR, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
+            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, T.bt_fa, wave, kWaves, wp, wp16, act, LD, kThetaRgb);
+            __syncthreads();
+            store_bwd<1, PREC>(accR, eR, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
+            store_bwd<1, PREC>(accA, eA, T.bt_fa.nt, wave, kWaves, hs, HLD, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
+            __syncthreads();
+        } else {
             f32x16 acc[2][1];
             EpiPre<1> e;
             acc_zero(acc);

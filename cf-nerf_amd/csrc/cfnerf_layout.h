@@ -48,8 +48,15 @@ inline const char* validate_cfg(const cfnerf_cfg& c) {
         return "netwidth must be a multiple of 64 in [64, 512]";
     if (c.multires < 1 || enc_ch(c.multires) > 64) return "multires must be in [1,10]";
     if (c.multires_views < 1 || enc_ch(c.multires_views) > 32) return "multires_views must be in [1,4]";
-    if (c.h_alpha_size != 32 && c.h_alpha_size != 64) return "h_alpha_size must be 32 or 64";
-    if (c.h_rgb_size != 32 && c.h_rgb_size != 64) return "h_rgb_size must be 32 or 64";
+    if (c.h_alpha_size < 32 || c.h_alpha_size > 128 || c.h_alpha_size % 32) return "h_alpha_size must be 32, 64, 96 or 128";
+    if (c.h_rgb_size < 32 || c.h_rgb_size > 128 || c.h_rgb_size % 32) return "h_rgb_size must be 32, 64, 96 or 128";
+    // the forward keeps h_rgb next to v in the in-place activation tile: columns [W/2, W/2 + h_rgb_size) of max(W, 128)
+    if (c.netwidth / 2 + c.h_rgb_size > (c.netwidth > 128 ? c.netwidth : 128))
+        return "h_rgb_size does not fit this netwidth (needs netwidth / 2 + h_rgb_size <= max(netwidth, 128))";
+    {   // LDS of the fused forward: act[64][max(W,128)+4] | hs[64][h_alpha+4] | row info, view encoding, reductions | comp[kMaxK][8]
+        const long lds = 4L * (64L * ((c.netwidth > 128 ? c.netwidth : 128) + 4) + 64L * (c.h_alpha_size + 4) + 68 * 4 + 32 + 16 + kMaxK * 8);
+        if (lds > 160 * 1024) return "h_alpha_size does not fit this netwidth (the forward's LDS tile would exceed the CU's 160 KB)";
+    }
     if (c.n_flows != 4) return "only n_flows == 4 is built";
     return nullptr;
 }

@@ -52,8 +52,8 @@ typedef struct cfnerf_cfg {
     int32_t netwidth;                   /* --netwidth   (256) a multiple of 64 in [64, 512] */
     int32_t multires;                   /* --multires   (10)  -> 63 input channels (run_nerf_helpers.py:54-69) */
     int32_t multires_views;             /* --multires_views (4) -> 27 channels */
-    int32_t h_alpha_size;               /* --h_alpha_size (32) 32 or 64 */
-    int32_t h_rgb_size;                 /* --h_rgb_size (64)  32 or 64 */
+    int32_t h_alpha_size;               /* --h_alpha_size (32) 32, 64, 96 or 128 */
+    int32_t h_rgb_size;                 /* --h_rgb_size (64)  32, 64, 96 or 128, with netwidth / 2 + h_rgb_size <= max(netwidth, 128) */
     int32_t n_flows;                    /* --n_flows    (4)   only 4 is built */
 } cfnerf_cfg;
 

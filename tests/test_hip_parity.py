@@ -61,6 +61,30 @@ def test_model_forward_vs_oracle(W, K, P):
     close(ent.reshape(-1)[0], ent_o, what="entropy")
 
 
+@pytest.mark.parametrize("W,ha,hr,K,N", [(256, 96, 128, 4, 20), (64, 128, 96, 3, 12), (512, 96, 128, 2, 6), (192, 96, 96, 5, 9), (256, 64, 96, 4, 10),
+                                         (128, 128, 32, 2, 8)])
+def test_head_sizes_96_and_128_vs_oracle(W, ha, hr, K, N):
+    """--h_alpha_size / --h_rgb_size (RUN:617-620 take any value): 32, 64, 96, 128 - model forward and a full render vs the oracle"""
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=ha, h_rgb_size=hr)
+    _, kw_train, _, model, p, _ = build_model(cfg, 300 + ha + hr)
+    g = torch.Generator().manual_seed(ha)
+    x = torch.rand(130, 90, generator=g) * 2 - 1
+    ea, er = torch.randn(K, 1, generator=g), torch.randn(K, 3, generator=g)
+    with torch.no_grad():
+        raw_t, ent = model.module(x.to(DEV), False, False, eps_alpha=ea, eps_rgb=er)
+    raw_o, ent_o = O.nerf_flows_forward(p, x, ea, er, cfg, is_test=False)
+    close(raw_t, raw_o, what="raw")
+    close(ent.reshape(-1)[0], ent_o, what="entropy")
+    rng = np.random.default_rng(N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    r = O.render(p, H, Wd, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=t_rand)
+    close(rgbs, r["rgb_map"], what="rgb_map")
+    close(depth, r["depth_map"], what="depth_map")
+
+
 # ---------------------------------------------------------------- raw2outputs (RUN:411-454)
 @pytest.mark.parametrize("wb", [False, True])
 def test_composite_vs_reference_golden(golden, wb):
@@ -434,7 +458,9 @@ def test_k_above_the_limit_and_bad_widths_are_rejected():
     with pytest.raises(RuntimeError, match="netwidth"):
         cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=576)))
     with pytest.raises(RuntimeError, match="h_alpha_size"):
-        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=64, h_alpha_size=96)))
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=64, h_alpha_size=160)))
+    with pytest.raises(RuntimeError, match="h_rgb_size"):
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=128, h_rgb_size=96)))      # 64 + 96 > max(128, 128)
 
 
 # ---------------------------------------------------------------- standalone boundary kernels

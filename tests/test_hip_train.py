@@ -126,6 +126,25 @@ def test_gradients_vs_oracle(W, K, N):
     check_all_grads(net, grad, grads, f"[W={W} K={K} N={N}, {n_flips} masks differ]")
 
 
+@pytest.mark.parametrize("W,ha,hr,K,N", [(256, 96, 128, 4, 14), (64, 128, 96, 3, 10), (512, 96, 128, 2, 5), (192, 96, 64, 5, 8), (128, 128, 64, 2, 9)])
+def test_gradients_with_head_sizes_96_and_128_vs_oracle(W, ha, hr, K, N):
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=ha, h_rgb_size=hr)
+    _, kw_train, _, model, p, _ = build_model(cfg, 800 + ha + hr)
+    net = model.module
+    rng = np.random.default_rng(ha + N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    tr = TR.Trainer(net, beta1=0.05)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 0.05)
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    check_all_grads(net, grad, grads, f"[W={W} ha={ha} hr={hr} K={K} N={N}, {n_flips} masks differ]")
+
+
 def test_train_step_k16_vs_reference_golden(golden):
     """G16: loss and every parameter gradient of the REAL reference at K = 16 latent samples."""
     g = golden("g16_train_k16")
@@ -534,7 +553,8 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     W = int(rng.choice([64, 128, 192, 256, 320]))
     D = int(rng.choice([4, 5, 6, 8]))
     K = int(rng.choice([2, 3, 4, 5, 6, 16, 32, 72]))
-    ha, hr = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
+    ha = int(rng.choice([32, 64, 96, 128] if W <= 256 else [32, 64, 96]))
+    hr = int(rng.choice([h for h in (32, 64, 96, 128) if W // 2 + h <= max(W, 128)]))
     N = int(rng.integers(3, 24))
     ndc = bool(rng.integers(0, 2))
     lindisp = (not ndc) and bool(rng.integers(0, 2))

@@ -10,9 +10,17 @@ cfg = O.OracleCfg(netwidth=256, K_samples=4)
 _, kw_train, kw_test, model, _, _ = build_model(cfg, 0)
 rays, (H, W, focal) = fern_rays(np.random.default_rng(0), 1024)
 rays = rays.cuda()
+TRAIN = os.environ.get("TL_MODE", "eval") == "train"
+if TRAIN:
+    from cfnerf_amd import train as TR
+    tr = TR.Trainer(model.module, beta1=0.01)
+    target = torch.rand(1024, 3, device="cuda")
 for _ in range(3):
-    with torch.no_grad(): cfnerf_amd.render(H, W, focal, rays=rays, **kw_test)
+    if TRAIN: tr.forward_backward(H, W, focal, rays, target)
+    else:
+        with torch.no_grad(): cfnerf_amd.render(H, W, focal, rays=rays, **kw_test)
 torch.cuda.synchronize()
+print("variant:", "train" if TRAIN else "eval")
 lib = L.lib()
 big = (C.c_ulonglong * 4096)()
 lib.cfnerf_debug_read_dbg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
