@@ -256,3 +256,27 @@ def test_three_optimizer_steps_through_the_unfused_path_follow_the_fused_path():
     np.testing.assert_allclose(lu, lf, rtol=2e-5, atol=2e-6)
     d = (pf - pu).abs()
     assert float((d > 1e-6).float().mean()) <= 1e-3 and float(d.max()) <= 3 * 2 * 5e-4 + 1e-6, (float(d.max()), float((d > 1e-6).float().mean()))
+
+
+def test_full_size_unfused_step_equals_the_fused_step_config2():
+    """BASELINE config 2 sizes through the unfused seam (P = 131 072 points in ONE points-mode stash, 2048 tiles): loss and every
+    gradient tensor equal the fused launch's (no oracle run needed at this size: the fused path is pinned elsewhere)."""
+    cfg, args, kw_train, model, p, rays, (H, Wd, focal), t_rand, ea, er, target = _problem(256, 4, 1024, seed=5)
+    net = model.module
+    q = kw_train["network_query_fn"]
+    common = dict(rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er)
+    grads, losses = [], []
+    for kw in (kw_train, dict(kw_train, network_query_fn=lambda *a, **k: q(*a, **k))):
+        net.flat.grad = None
+        rgb, _, _, ex = cfnerf_amd.render(H, Wd, focal, **common, **kw)
+        loss = _loss_like_the_reference(rgb, ex, target.to(DEV), 4, 0.01)
+        loss.backward()
+        grads.append(net.flat.grad.clone()); losses.append(float(loss.detach()))
+    assert abs(losses[0] - losses[1]) <= 1e-6 * max(1.0, abs(losses[0]))
+    for key, (off, cnt) in net.layout.items():
+        a, b = grads[1][off:off + cnt], grads[0][off:off + cnt]
+        if float(b.abs().max()) > 0:
+            assert _rel_to_max(a, b) <= 2e-6, (key, _rel_to_max(a, b))
+        else:
+            assert not a.any(), key
+    net.release_workspace()
