@@ -1514,9 +1514,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
         ta.d_rgb = d_out; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
         ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
-        // k-parts: the kernel runs ONE wave per SIMD, so split only while the waves still fit in one round (measured: a
-        // second round costs more than the shorter k-loops save); at most kTailParts and never more than K / 2
-        while (ksplit < kTailParts && ksplit * 2 <= q.K && N * ksplit * 2 <= (int64_t)m->n_cu * 4) ksplit *= 2;
+        ksplit = tail_parts(N, q.K, std::min(m->n_cu, kMaxCu));      // (never more parts than the workspace was carved for)
         ta.ksplit = ksplit;
         gms_rows = N * ksplit;
         hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((N * ksplit + kWaves - 1) / kWaves)), dim3(kThreads), 0, st, ta);

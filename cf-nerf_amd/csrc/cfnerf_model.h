@@ -16,6 +16,14 @@ constexpr int kFwdRing = 64;    // event pairs kept for the forward launch (mean
 constexpr int kDwSlots = 128;   // split-K slots of the weight-gradient partials (upper bound of any split count)
 constexpr int kMaxDwTiles = 256, kMaxDwBlocks = 16384;     // descriptor capacities carved out of the workspace
 constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over up to this many waves (partial g_theta buffers)
+// k-parts of the tail kernel for a batch: it runs ONE wave per SIMD, so a ray's latents are split over more waves only while all
+// waves still fit in one round (measured: a second round costs more than the shorter k-loops save); at most kTailParts, never more
+// than K / 2.  The workspace is carved for the CU count's upper bound (kMaxCu), the launch uses the device's own.
+inline int tail_parts(int64_t n_rays, int k, int n_cu) {
+    int parts = 1;
+    while (parts < kTailParts && parts * 2 <= k && n_rays * parts * 2 <= (int64_t)n_cu * 4) parts *= 2;
+    return parts;
+}
 
 // Everything a CFNERF_F_STASH forward keeps for cfnerf_render_bwd plus every buffer the backward writes, carved out of
 // ONE block of device memory: either handed in by the caller (cfnerf_model_set_workspace, sized with
@@ -87,7 +95,7 @@ struct Stash {
         take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
         take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
         take(&t->gms, (size_t)(std::max<int64_t>(n * kTailParts, tiles) + 8) * 8, 4);      // rays * k-parts (fused tail) or waves of points (flows_bwd)
-        take(&t->g_theta, (size_t)kTailParts * P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);
+        take(&t->g_theta, (size_t)tail_parts(n, k, kMaxCu) * P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);      // one partial per k-part
         take(&t->g_ha, (size_t)P * c.h_alpha_size, 4); take(&t->g_v, (size_t)P * (W / 2), 4);
         take(&t->g_feat, (size_t)P * W, 4); take(&t->g_h, (size_t)D * P * W, 4);
         take(&t->dbp, (size_t)n_wg * nb, 4);
