@@ -42,7 +42,9 @@ struct DwTile {
     int32_t dst_ld, dst_col;
     int32_t gk, wk;                                       // small kernel: waves along k, k-tiles per wave (GN = 8 / gk);
                                                           // big kernel: gk = wave arrangement (0: 2 x 4, 1: 1 x 8 for N <= 128)
-    int32_t nsplit, pad_;                                 // point splits of this tile (blocks per tile)
+    int32_t nsplit;                                       // point splits of this tile (blocks per tile)
+    int32_t row_f;                                        // 0, or (theta-head tiles) the model's n_flows: dY column 4 b + f is destination row b F + f of
+                                                          // the concatenated heads, columns with f >= n_flows are dropped (cfnerf_layout.h)
 };
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };

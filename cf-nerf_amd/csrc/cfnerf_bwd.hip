@@ -1029,8 +1029,14 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
     const int k = k_base + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int n = n_base + frag_row(r, lane);
-        if (n < t.N && k < t.K) {
+        int n = n_base + frag_row(r, lane);
+        bool live = n < t.N && k < t.K;
+        if (t.row_f) {                                          // theta-head tile: kernel column 4 b + f -> row b F + f, f >= F dropped
+            const int f = n & (kFlowsMax - 1);
+            live = live && f < t.row_f;
+            n = (n >> 2) * t.row_f + f;
+        }
+        if (live) {
             int sg = 0;
             if (t.nseg > 1 && n >= t.seg_row[1]) sg = 1;
             if (t.nseg > 2 && n >= t.seg_row[2]) sg = 2;
@@ -1225,13 +1231,17 @@ int cfnerf::ensure_bwd_plan(cfnerf_model* m) {
     bmap(B.db_v, W / 2, "views_linears.0.bias");
     bmap(B.db_ha, HA, "h_alpha_linear.bias");
     bmap(B.db_hr, HR, "h_rgb_linear.bias");
-    bmap(B.db_theta + 0, 9 * F, "flows_rgb.amor_d.bias");
-    bmap(B.db_theta + 9 * F, 3 * F, "flows_rgb.amor_diag1.0.bias");
-    bmap(B.db_theta + 12 * F, 3 * F, "flows_rgb.amor_diag2.0.bias");
-    bmap(B.db_theta + 15 * F, 3 * F, "flows_rgb.amor_b.bias");
-    bmap(B.db_theta + kThetaRgb + 0, F, "flows_alpha.amor_diag1.0.bias");
-    bmap(B.db_theta + kThetaRgb + F, F, "flows_alpha.amor_diag2.0.bias");
-    bmap(B.db_theta + kThetaRgb + 2 * F, F, "flows_alpha.amor_b.bias");
+    {   // theta heads: one map per block of F rows (kernel columns base + 4 b + f)
+        const char* kr[4] = {"flows_rgb.amor_d.bias", "flows_rgb.amor_diag1.0.bias", "flows_rgb.amor_diag2.0.bias", "flows_rgb.amor_b.bias"};
+        const int base_r[4] = {0, 9 * kFlowsMax, 12 * kFlowsMax, 15 * kFlowsMax}, blocks_r[4] = {9, 3, 3, 3};
+        for (int i = 0; i < 4; ++i)
+            for (int b = 0; b < blocks_r[i]; ++b) {
+                BiasMap bm; bm.col0 = B.db_theta + base_r[i] + kFlowsMax * b; bm.count = F; bm.dst = (uint32_t)(L.off(kr[i]) + b * F);
+                B.bias_maps.push_back(bm);
+            }
+        const char* ka[3] = {"flows_alpha.amor_diag1.0.bias", "flows_alpha.amor_diag2.0.bias", "flows_alpha.amor_b.bias"};
+        for (int i = 0; i < 3; ++i) bmap(B.db_theta + kThetaRgb + kFlowsMax * i, F, ka[i]);
+    }
     B.built = true;
     return 0;
 }
@@ -1239,7 +1249,7 @@ int cfnerf::ensure_bwd_plan(cfnerf_model* m) {
 // one weight-gradient job -> tiles: 256 x 256 ("big" kernel) when the job is at least 128 x 128; else ("small" kernel)
 // tiles of (32 GN) x (32 GK WK), GN GK = 8 waves, with the wave arrangement picked from the job's shape
 static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const float* dY, int ldY, int Nread, int N, const float* X,
-                    int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col) {
+                    int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col, int row_f = 0) {
     const bool is_big = N >= 128 && Kvalid >= 128;
     int gk = 0, wk = 0;
     if (!is_big) {          // wave arrangement GN x GK (GN GK = 8) from the job's K; a tile stages at most 128 + 64 or 64 + 128 columns
@@ -1254,7 +1264,7 @@ static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
             t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
             t.nseg = nseg;
             for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
-            t.dst_ld = dst_ld; t.dst_col = dst_col;
+            t.dst_ld = dst_ld; t.dst_col = dst_col; t.row_f = row_f;
             (is_big ? big : small).push_back(t);
         }
 }
@@ -1293,13 +1303,13 @@ static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
         const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
         const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
                                  (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
-        add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * F, q.hr, HR, HR, HR, 4, rows, dst, HR, 0);
+        add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * kFlowsMax, q.hr, HR, HR, HR, 4, rows, dst, HR, 0, F);      // dY columns in the kernels' 4-step map
     }
     {
         const int rows[3] = {0, F, 2 * F};
         const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
                                  (uint32_t)L.off("flows_alpha.amor_b.weight")};
-        add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * F, q.ha, HA, HA, HA, 3, rows, dst, HA, 0);
+        add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * kFlowsMax, q.ha, HA, HA, HA, 3, rows, dst, HA, 0, F);
     }
 }
 
@@ -1656,7 +1666,7 @@ extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
             int32_t* o = tiles_out + 16 * n;
             o[0] = pass == 0; o[1] = t.n0; o[2] = t.k0; o[3] = t.N; o[4] = t.K; o[5] = t.gk; o[6] = t.wk; o[7] = t.nseg;
             for (int g = 0; g < 4; ++g) { o[8 + g] = t.seg_row[g]; segdst_out[4 * n + g] = t.seg_dst[g]; }
-            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = o[15] = 0;
+            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = t.row_f; o[15] = 0;
             ++n;
         }
     return n;

@@ -15,6 +15,7 @@ namespace cfnerf {
 
 constexpr int kMaxDepth = 16;
 constexpr int kTileM = 64;            // rows (points) per workgroup tile
+constexpr int kFlowsMax = 4;         // flow steps the kernels are built for (--n_flows 1 .. 4: see the theta column map below)
 constexpr int kMaxK = 128;            // latent samples per point supported by the fused kernels (the reference's default K_samples is 64, RUN:631)
 
 struct ParamEntry {
@@ -57,7 +58,7 @@ inline const char* validate_cfg(const cfnerf_cfg& c) {
         const long lds = 4L * (64L * ((c.netwidth > 128 ? c.netwidth : 128) + 4) + 64L * (c.h_alpha_size + 4) + 68 * 4 + 32 + 16 + kMaxK * 8);
         if (lds > 160 * 1024) return "h_alpha_size does not fit this netwidth (the forward's LDS tile would exceed the CU's 160 KB)";
     }
-    if (c.n_flows != 4) return "only n_flows == 4 is built";
+    if (c.n_flows < 1 || c.n_flows > kFlowsMax) return "n_flows must be in [1,4]";
     return nullptr;
 }
 
@@ -113,9 +114,13 @@ struct SubL {
     uint16_t pad_;
 };
 
-// theta (flow-parameter) column map inside a tile row: rgb heads [0,96), alpha heads [96,128)
-//   rgb:   [0,9F) amor_d (i*3+j)*F+f | [9F,12F) diag1 i*F+f | [12F,15F) diag2 | [15F,18F) b
-//   alpha: 96 + [0,F) diag1 | [F,2F) diag2 | [2F,3F) b         (amor_d of z=1 is fully masked: MOD:327,374)
+// theta (flow-parameter) column map inside a tile row: rgb heads [0,96), alpha heads [96,128).  The kernels are built for
+// kFlowsMax = 4 flow steps and address a parameter of step f as (block) * 4 + f:
+//   rgb:   [0,36) amor_d (i*3+j)*4+f | [36,48) diag1 i*4+f | [48,60) diag2 | [60,72) b
+//   alpha: 96 + [0,4) diag1 | [4,8) diag2 | [8,12) b            (amor_d of z=1 is fully masked: MOD:327,374)
+// A model with n_flows = F < 4 (--n_flows, RUN:622) keeps that map: its nn.Linear rows (block) * F + f go to columns (block) * 4 + f,
+// the columns of the steps f >= F stay zero in every packed operand, and a step whose parameters are all zero is the identity with
+// log-det 0 (z + 0 * tanh(0): FLW:225-268) - so the same kernels run it.  Their gradient columns are computed and dropped.
 constexpr int kThetaRgb = 96;
 constexpr int kThetaAll = 128;
 
@@ -124,7 +129,7 @@ constexpr int kMaxCu = 256;           // gfx950 has 256 CUs; per-workgroup parti
 inline int bias_partial_cols(const cfnerf_cfg& c) {
     return c.netdepth * c.netwidth + c.netwidth + c.netwidth / 2 + pad_to(c.h_alpha_size, 32) + pad_to(c.h_rgb_size, 32) + kThetaAll;
 }
-inline int bias_map_count(const cfnerf_cfg& c) { return c.netdepth + 4 + 7; }
+inline int bias_map_count(const cfnerf_cfg& c) { return c.netdepth + 4 + 21; }      // trunk | feature, views, h_alpha, h_rgb | 18 + 3 theta blocks
 
 struct NetTab {
     // forward
@@ -215,20 +220,20 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
         if (bias) { s.b_off = cur; cur += (uint32_t)s.nt * 32; } else s.b_off = 0xffffffffu;
         return s;
     };
-    auto piece = [&](const SubL& s, const char* key, int col0, int ncols, int out_off, int red_off, bool transpose) {
+    auto piece = [&](const SubL& s, const char* key, int col0, int ncols, int out_off, int red_off, bool transpose, int row0 = 0, int nrows = -1) {
         const ParamEntry* e = L.find(key);
         PackDesc d{};
-        d.src_off = (uint32_t)(e->off + col0); d.src_ld = (uint32_t)e->cols; d.n_rows = (uint32_t)e->rows;
+        d.src_off = (uint32_t)(e->off + (int64_t)row0 * e->cols + col0); d.src_ld = (uint32_t)e->cols; d.n_rows = (uint32_t)(nrows < 0 ? e->rows : nrows);
         d.n_cols = (uint32_t)ncols; d.dst_off = s.w_off; d.kc = s.kc; d.out_off = out_off; d.red_off = red_off;
         d.dst16_off = s.w16_off; d.kc16 = s.kc16;
         d.transpose = transpose ? 1 : 0; d.first_elem = P.total_elems;
         P.total_elems += d.n_rows * d.n_cols;
         P.descs.push_back(d);
     };
-    auto bias_piece = [&](const SubL& s, const char* key, int out_off) {
+    auto bias_piece = [&](const SubL& s, const char* key, int out_off, int row0 = 0, int nrows = -1) {
         const ParamEntry* e = L.find(key);
         PackDesc d{};
-        d.src_off = (uint32_t)e->off; d.src_ld = 0; d.n_rows = (uint32_t)e->rows; d.n_cols = 0;
+        d.src_off = (uint32_t)(e->off + row0); d.src_ld = 0; d.n_rows = (uint32_t)(nrows < 0 ? e->rows : nrows); d.n_cols = 0;
         d.dst_off = s.b_off; d.kc = 0; d.out_off = out_off; d.red_off = 0; d.transpose = 0; d.first_elem = P.total_elems;
         P.total_elems += d.n_rows;
         P.descs.push_back(d);
@@ -262,34 +267,34 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
     piece(T.vd, "views_linears.0.weight", W, icv, 0, 0, false);
     T.hr = alloc_op(c.h_rgb_size, W / 2, true);
     piece(T.hr, "h_rgb_linear.weight", 0, W / 2, 0, 0, false); bias_piece(T.hr, "h_rgb_linear.bias", 0);
+    // theta heads: block b of a head tensor = its rows [b F, (b + 1) F) -> columns base + 4 b + f (see the column map above)
+    const char* ks_r[4] = {"flows_rgb.amor_d", "flows_rgb.amor_diag1.0", "flows_rgb.amor_diag2.0", "flows_rgb.amor_b"};
+    const int base_r[4] = {0, 9 * kFlowsMax, 12 * kFlowsMax, 15 * kFlowsMax}, blocks_r[4] = {9, 3, 3, 3};
+    const char* ks_a[3] = {"flows_alpha.amor_diag1.0", "flows_alpha.amor_diag2.0", "flows_alpha.amor_b"};
     T.fr = alloc_op(kThetaRgb, c.h_rgb_size, true);
-    {
-        const char* ks[4] = {"flows_rgb.amor_d", "flows_rgb.amor_diag1.0", "flows_rgb.amor_diag2.0", "flows_rgb.amor_b"};
-        const int offs[4] = {0, 9 * F, 12 * F, 15 * F};
-        for (int i = 0; i < 4; ++i) {
-            std::snprintf(kw, sizeof kw, "%s.weight", ks[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks[i]);
-            piece(T.fr, kw, 0, c.h_rgb_size, offs[i], 0, false); bias_piece(T.fr, kb, offs[i]);
+    for (int i = 0; i < 4; ++i) {
+        std::snprintf(kw, sizeof kw, "%s.weight", ks_r[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks_r[i]);
+        for (int b = 0; b < blocks_r[i]; ++b) {
+            piece(T.fr, kw, 0, c.h_rgb_size, base_r[i] + kFlowsMax * b, 0, false, b * F, F);
+            bias_piece(T.fr, kb, base_r[i] + kFlowsMax * b, b * F, F);
         }
     }
     T.fa = alloc_op(kThetaAll - kThetaRgb, c.h_alpha_size, true);
-    {
-        const char* ks[3] = {"flows_alpha.amor_diag1.0", "flows_alpha.amor_diag2.0", "flows_alpha.amor_b"};
-        for (int i = 0; i < 3; ++i) {
-            std::snprintf(kw, sizeof kw, "%s.weight", ks[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks[i]);
-            piece(T.fa, kw, 0, c.h_alpha_size, i * F, 0, false); bias_piece(T.fa, kb, i * F);
-        }
+    for (int i = 0; i < 3; ++i) {
+        std::snprintf(kw, sizeof kw, "%s.weight", ks_a[i]); std::snprintf(kb, sizeof kb, "%s.bias", ks_a[i]);
+        piece(T.fa, kw, 0, c.h_alpha_size, kFlowsMax * i, 0, false, 0, F);
+        bias_piece(T.fa, kb, kFlowsMax * i, 0, F);
     }
     // ---- backward-data operands: dX[., in] = sum_out dY[., out] * W[out][in]  -> out index = col, red index = row
     T.bt_fr = alloc_op(c.h_rgb_size, kThetaRgb, false);
-    {
-        const char* ks[4] = {"flows_rgb.amor_d.weight", "flows_rgb.amor_diag1.0.weight", "flows_rgb.amor_diag2.0.weight", "flows_rgb.amor_b.weight"};
-        const int offs[4] = {0, 9 * F, 12 * F, 15 * F};
-        for (int i = 0; i < 4; ++i) piece(T.bt_fr, ks[i], 0, c.h_rgb_size, 0, offs[i], true);
+    for (int i = 0; i < 4; ++i) {
+        std::snprintf(kw, sizeof kw, "%s.weight", ks_r[i]);
+        for (int b = 0; b < blocks_r[i]; ++b) piece(T.bt_fr, kw, 0, c.h_rgb_size, 0, base_r[i] + kFlowsMax * b, true, b * F, F);
     }
     T.bt_fa = alloc_op(c.h_alpha_size, kThetaAll - kThetaRgb, false);
-    {
-        const char* ks[3] = {"flows_alpha.amor_diag1.0.weight", "flows_alpha.amor_diag2.0.weight", "flows_alpha.amor_b.weight"};
-        for (int i = 0; i < 3; ++i) piece(T.bt_fa, ks[i], 0, c.h_alpha_size, 0, i * F, true);
+    for (int i = 0; i < 3; ++i) {
+        std::snprintf(kw, sizeof kw, "%s.weight", ks_a[i]);
+        piece(T.bt_fa, kw, 0, c.h_alpha_size, 0, kFlowsMax * i, true, 0, F);
     }
     T.bt_hr = alloc_op(W / 2, c.h_rgb_size, false);
     piece(T.bt_hr, "h_rgb_linear.weight", 0, W / 2, 0, 0, true);

@@ -54,7 +54,7 @@ typedef struct cfnerf_cfg {
     int32_t multires_views;             /* --multires_views (4) -> 27 channels */
     int32_t h_alpha_size;               /* --h_alpha_size (32) 32, 64, 96 or 128 */
     int32_t h_rgb_size;                 /* --h_rgb_size (64)  32, 64, 96 or 128, with netwidth / 2 + h_rgb_size <= max(netwidth, 128) */
-    int32_t n_flows;                    /* --n_flows    (4)   only 4 is built */
+    int32_t n_flows;                    /* --n_flows    (4)   1 .. 4 (fewer than 4 steps run as 4 with the missing steps' parameters zero: identity steps) */
 } cfnerf_cfg;
 
 typedef struct cfnerf_model cfnerf_model;   /* opaque: packed weights + workspaces for ONE device */

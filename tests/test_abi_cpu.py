@@ -28,9 +28,10 @@ def test_library_exports_every_declared_symbol():
 
 @pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64), (192, 32, 64), (320, 64, 32), (448, 32, 32), (256, 96, 128), (64, 128, 96)])
 def test_flat_layout_is_state_dict_order(W, ha, hr):
-    cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
+    F = 4 if W != 192 else 3                      # one case with --n_flows other than the default
+    cfg = L.Cfg(8, W, 10, 4, ha, hr, F)
     lay, total = cfnerf_amd.param_layout(cfg)
-    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr)
+    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr, n_flows=F)
     shapes = O.param_shapes(ocfg)
     assert list(lay.keys()) == list(shapes.keys())
     off = 0
@@ -44,7 +45,7 @@ def test_flat_layout_is_state_dict_order(W, ha, hr):
 
 def test_unsupported_configs_are_rejected_loudly():
     lib = L.lib()
-    for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 3), L.Cfg(8, 256, 11, 4, 32, 64, 4),
+    for bad in (L.Cfg(8, 200, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 32, 64, 5), L.Cfg(8, 256, 10, 4, 32, 64, 0), L.Cfg(8, 256, 11, 4, 32, 64, 4),
                 L.Cfg(2, 256, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 48, 64, 4), L.Cfg(8, 576, 10, 4, 32, 64, 4), L.Cfg(8, 0, 10, 4, 32, 64, 4), L.Cfg(8, 256, 10, 4, 160, 64, 4), L.Cfg(8, 128, 10, 4, 32, 96, 4), L.Cfg(8, 512, 10, 4, 128, 64, 4)):
         assert lib.cfnerf_param_count(C.byref(bad)) < 0
         assert lib.cfnerf_last_error() != b""
@@ -62,11 +63,21 @@ def _decode(packed, w_off, kc, nt):
     return M
 
 
-@pytest.mark.parametrize("W,ha,hr", [(64, 32, 64), (256, 32, 64), (128, 64, 32), (192, 32, 64), (384, 64, 64), (256, 96, 128), (64, 128, 96)])
-def test_packed_operands_decode_to_the_weights(W, ha, hr):
+def _to_kernel_columns(M, F):
+    """rows (block) * F + f of a theta-head matrix -> rows (block) * 4 + f of the kernels' 4-step column map (zero rows for f >= F)"""
+    blocks = M.shape[0] // F
+    out = np.zeros((blocks * 4,) + M.shape[1:], M.dtype)
+    for b in range(blocks):
+        out[4 * b:4 * b + F] = M[F * b:F * b + F]
+    return out
+
+
+@pytest.mark.parametrize("W,ha,hr,F", [(64, 32, 64, 4), (256, 32, 64, 4), (128, 64, 32, 4), (192, 32, 64, 4), (384, 64, 64, 4), (256, 96, 128, 4), (64, 128, 96, 4),
+                                       (256, 32, 64, 3), (128, 32, 64, 2), (64, 64, 32, 1)])
+def test_packed_operands_decode_to_the_weights(W, ha, hr, F):
     lib = C.CDLL(L.LIB_PATH)
-    cfg = L.Cfg(8, W, 10, 4, ha, hr, 4)
-    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr)
+    cfg = L.Cfg(8, W, 10, 4, ha, hr, F)
+    ocfg = O.OracleCfg(netwidth=W, h_alpha_size=ha, h_rgb_size=hr, n_flows=F)
     p = {k: v.numpy() for k, v in O.make_params(ocfg, 5).items()}
     flat = np.concatenate([p[k].reshape(-1) for k in O.param_shapes(ocfg)]).astype(np.float32)
     lib.cfnerf_debug_packed_floats.restype = C.c_int64
@@ -111,9 +122,11 @@ def test_packed_operands_decode_to_the_weights(W, ha, hr):
                          p["flows_rgb.amor_diag2.0.weight"], p["flows_rgb.amor_b.weight"]], 0)
     frb = np.concatenate([p["flows_rgb.amor_d.bias"], p["flows_rgb.amor_diag1.0.bias"],
                           p["flows_rgb.amor_diag2.0.bias"], p["flows_rgb.amor_b.bias"]], 0)
+    fr, frb = _to_kernel_columns(fr, F), _to_kernel_columns(frb, F)       # n_flows < 4: the missing steps' columns stay zero
     M, b = op("fr"); expect(M, fr, "fr"); assert np.array_equal(b[:72], frb) and not b[72:].any()
     fa = np.concatenate([p["flows_alpha.amor_diag1.0.weight"], p["flows_alpha.amor_diag2.0.weight"],
                          p["flows_alpha.amor_b.weight"]], 0)
+    fa = _to_kernel_columns(fa, F)
     M, b = op("fa"); expect(M, fa, "fa")
     # backward-data operands are the transposes
     M, _ = op("bt_fr"); expect(M, fr.T, "bt_fr")
@@ -163,13 +176,14 @@ def test_seeded_construction_replays_the_reference_rng_stream(golden, tag):
 
 @pytest.mark.parametrize("W,D,ha,hr", [(256, 8, 32, 64), (64, 8, 32, 64), (128, 6, 32, 32), (512, 8, 64, 64), (256, 3, 64, 32), (512, 16, 32, 64), (192, 8, 32, 64), (320, 8, 32, 64),
                                        (384, 6, 64, 32), (448, 8, 32, 64), (256, 8, 96, 128), (64, 8, 128, 96), (512, 8, 96, 128)])
-def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
+@pytest.mark.parametrize("F", [4, 3, 1])
+def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr, F):
     """Host logic of the backward: the big / small dW tiles (wave arrangement GN x GK of the small kernel included)
     must write every live weight element exactly once per split slot and never touch biases or dead tensors."""
     lib = L.lib()
     lib.cfnerf_debug_dw_plan.restype = C.c_int
     lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
-    cfg = L.Cfg(D, W, 10, 4, ha, hr, 4)
+    cfg = L.Cfg(D, W, 10, 4, ha, hr, F)
     cap = 4096
     tiles = (C.c_int32 * (16 * cap))()
     segdst = (C.c_uint32 * (4 * cap))()
@@ -192,6 +206,9 @@ def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr):
         ns = np.arange(n0, min(N, n0 + rows))
         ks = np.arange(k0, min(K, k0 + cols))
         assert len(ns) and len(ks), "empty tile"
+        row_f = int(row[14])
+        if row_f:               # theta-head tile: dY column 4 b + f -> row b F + f of the concatenated heads, f >= F dropped
+            ns = np.array([(n >> 2) * row_f + (n & 3) for n in ns if (n & 3) < row_f])
         seg = np.zeros_like(ns)
         for g in range(1, nseg):
             seg[ns >= seg_row[g]] = g

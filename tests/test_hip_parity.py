@@ -85,6 +85,36 @@ def test_head_sizes_96_and_128_vs_oracle(W, ha, hr, K, N):
     close(depth, r["depth_map"], what="depth_map")
 
 
+@pytest.mark.parametrize("F,W,K,N", [(1, 64, 3, 10), (2, 256, 4, 14), (3, 128, 5, 9), (3, 512, 16, 5)])
+def test_n_flows_other_than_four_vs_oracle(F, W, K, N):
+    """--n_flows (RUN:622) 1 .. 3: the kernels are built for four flow steps; a shorter stack runs as four with the missing steps'
+    parameters zero in every packed operand (identity steps, log-det 0) - model forward, entropy and a full render vs the oracle"""
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, n_flows=F, h_alpha_size=64 if W == 512 else 32)
+    _, kw_train, _, model, p, _ = build_model(cfg, 400 + F)
+    assert model.module.n_flows == F and tuple(model.module.view("flows_rgb.amor_d.weight").shape) == (9 * F, cfg.h_rgb_size)
+    g = torch.Generator().manual_seed(F)
+    x = torch.rand(150, 90, generator=g) * 2 - 1
+    ea, er = torch.randn(K, 1, generator=g), torch.randn(K, 3, generator=g)
+    with torch.no_grad():
+        raw_t, ent = model.module(x.to(DEV), False, False, eps_alpha=ea, eps_rgb=er)
+        raw_e, _ = model.module(x.to(DEV), False, True, eps_alpha=ea, eps_rgb=er)
+    raw_o, ent_o = O.nerf_flows_forward(p, x, ea, er, cfg, is_test=False)
+    close(raw_t, raw_o, what="raw")
+    close(raw_e, raw_o, what="raw (eval branch)")
+    close(ent.reshape(-1)[0], ent_o, what="entropy")
+    rng = np.random.default_rng(N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    with torch.no_grad():
+        rgbs, disp, depth, extras = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    r = O.render(p, H, Wd, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=t_rand)
+    close(rgbs, r["rgb_map"], what="rgb_map")
+    close(depth, r["depth_map"], what="depth_map")
+    close(extras["loss_entropy"].mean(), r["loss_entropy"], what="loss_entropy")
+    with pytest.raises(RuntimeError, match="n_flows"):
+        cfnerf_amd.create_nerf(make_args(O.OracleCfg(netwidth=64, n_flows=5)))
+
+
 # ---------------------------------------------------------------- raw2outputs (RUN:411-454)
 @pytest.mark.parametrize("wb", [False, True])
 def test_composite_vs_reference_golden(golden, wb):

@@ -145,6 +145,34 @@ def test_gradients_with_head_sizes_96_and_128_vs_oracle(W, ha, hr, K, N):
     check_all_grads(net, grad, grads, f"[W={W} ha={ha} hr={hr} K={K} N={N}, {n_flips} masks differ]")
 
 
+@pytest.mark.parametrize("F,W,K,N", [(1, 64, 3, 12), (2, 256, 4, 16), (3, 128, 5, 10), (3, 512, 16, 4)])
+def test_gradients_with_n_flows_other_than_four_vs_oracle(F, W, K, N):
+    """a shorter flow stack (--n_flows 1 .. 3) through the four-step kernels: every gradient vs the oracle, nothing leaks into or out
+    of the padded steps (their gradient columns are computed and dropped)"""
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, n_flows=F, h_alpha_size=64 if W == 512 else 32)
+    _, kw_train, _, model, p, _ = build_model(cfg, 850 + F)
+    net = model.module
+    rng = np.random.default_rng(F + N)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    tr = TR.Trainer(net, beta1=0.05)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 0.05)
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    check_all_grads(net, grad, grads, f"[n_flows={F} W={W} K={K} N={N}, {n_flips} masks differ]")
+    # and one Adam step + re-pack keeps the padded columns zero: a second forward still matches the oracle after its own update
+    tr.step(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV))
+    sd = {k[len("module."):]: v.cpu() for k, v in model.state_dict().items() if k[len("module."):] in p}
+    with torch.no_grad():
+        rgb2 = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)[0]
+    r2 = O.render(sd, H, Wd, focal, cfg, ea, er, True, rays=(rays[0], rays[1]), t_rand=t_rand)
+    close(rgb2, r2["rgb_map"], what="rgb_map after one step")
+
+
 def test_train_step_k16_vs_reference_golden(golden):
     """G16: loss and every parameter gradient of the REAL reference at K = 16 latent samples."""
     g = golden("g16_train_k16")
@@ -560,7 +588,8 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     lindisp = (not ndc) and bool(rng.integers(0, 2))
     wb = bool(rng.integers(0, 2))
     perturb = bool(rng.integers(0, 4))                   # mostly on
-    cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr)
+    nf = int(rng.choice([4, 4, 4, 3, 2]))
+    cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr, n_flows=nf)
     _, kw_train, _, model, p, _ = build_model(cfg, 700 + seed, no_ndc=not ndc, lindisp=lindisp, white_bkgd=wb)
     net = model.module
     rays, (H, Wd, focal) = fern_rays(rng, N)
@@ -576,7 +605,7 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
                                perturb=1. if perturb else 0.).cpu()
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
     scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb)
-    what = f"[W={W} D={D} K={K} ha={ha} hr={hr} N={N} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
+    what = f"[W={W} D={D} K={K} ha={ha} hr={hr} F={nf} N={N} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
     close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map " + what)
     close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)
