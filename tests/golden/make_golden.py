@@ -495,6 +495,49 @@ def main():
             g16["grad." + k[len("module."):]] = v.grad.clone()
     out["g16_train_k16"] = g16
 
+    # ---------------- G17: a train step OUTSIDE the shipped configurations - netwidth 192, netdepth 6, n_flows 3, h_alpha 96,
+    #                  h_rgb 96 (RUN:582-622 take any value): pins the widened configuration space of the build to the real reference ---
+    rng17 = np.random.default_rng(117)
+    cfg = O.OracleCfg(netwidth=192, netdepth=6, K_samples=3, n_flows=3, h_alpha_size=96, h_rgb_size=96)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 65, tmp, K_samples=3)
+    net = model.module
+    n = 10
+    rays, (H, W, focal) = fern_rays(rng17, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng17.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    t_rand = torch.tensor(rng17.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng17.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng17.standard_normal((3, 3)), dtype=torch.float32)
+    with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
+    nk, eps, beta1 = 3, 1e-05, 0.02
+    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, _ = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., **kw_test)
+    g17 = dict(seed=65, netwidth=192, netdepth=6, K=3, n_flows=3, h_alpha_size=96, h_rgb_size=96, H=H, W=W, focal=focal, rays=rays_t,
+               target=target, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, beta1=beta1, rgb_map=rgbs, depth_map=depth, disp_map=disp,
+               raw_first2=extras["raw"][:2], loss=loss.detach(), loss_nll=loss_nll.detach(), loss_entropy=extras["loss_entropy"].mean().detach(),
+               rgb_map_eval=rgbs_e, depth_map_eval=depth_e,
+               state_dict_keys=np.array([k[len("module."):] for k in model.state_dict().keys()]))
+    for k, v in model.named_parameters():
+        k = k[len("module."):]
+        if v.grad is None:
+            continue
+        if v.grad.numel() > 8192:            # the big trunk weights: first two rows + Frobenius norm keep the fixture small
+            g17["gradrows." + k] = v.grad[:2].clone()
+            g17["gradnorm." + k] = v.grad.double().norm()
+        else:
+            g17["grad." + k] = v.grad.clone()
+    out["g17_train_wide_config"] = g17
+
     import hashlib
     import json
     argv = sys.argv[1:]

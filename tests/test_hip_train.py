@@ -45,7 +45,8 @@ def check_all_grads(net, grad, grads, what=""):
 
 
 def cfg_from(g):
-    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]))
+    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g.get("netdepth", 8)), n_flows=int(g.get("n_flows", 4)),
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
 
 
 @pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
@@ -198,6 +199,49 @@ def test_train_step_k16_vs_reference_golden(golden):
         else:
             assert not grad[off:off + cnt].any(), key
     assert n >= 30
+
+
+def test_train_step_wide_config_vs_reference_golden(golden):
+    """G17: a train step of the REAL reference outside the shipped configurations - netwidth 192, netdepth 6, n_flows 3, h_alpha 96,
+    h_rgb 96: outputs, loss, entropy and every parameter gradient (the big trunk weights as two rows + norm), eval render"""
+    g = golden("g17_train_wide_config")
+    cfg = cfg_from(g)
+    assert (cfg.netwidth, cfg.netdepth, cfg.n_flows, cfg.h_alpha_size, cfg.h_rgb_size) == (192, 6, 3, 96, 96)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]))
+    net = model.module
+    assert sorted(k[len("module."):] for k in model.state_dict().keys()) == sorted(g["state_dict_keys"])       # (buffers sit elsewhere in the order)
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    tr = TR.Trainer(net, beta1=float(g["beta1"]))
+    eps = torch.cat([T(g["eps_rgb"]), T(g["eps_alpha"])], -1).to(DEV)
+    grad = tr.forward_backward(H, W, focal, T(g["rays"]).to(DEV), T(g["target"]).to(DEV), t_rand=T(g["t_rand"]).to(DEV), eps=eps).cpu()
+    close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    close(tr.depth, g["depth_map"], what="depth_map")
+    close(tr.scalars[0].cpu(), g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    close(tr.scalars[1].cpu(), g["loss_nll"], atol=1e-5, rtol=1e-4, what="loss_nll")
+    close(tr.entropy.cpu().reshape(()), g["loss_entropy"], atol=1e-5, rtol=1e-4, what="entropy")
+    packed = O.pack_rays(H, W, focal, T(g["rays"])[0], T(g["rays"])[1], True, 0., 1.)
+    corr, _ = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    n = 0
+    for key, (off, cnt) in net.layout.items():
+        gk = grad[off:off + cnt].numpy()
+        if ("grad." + key) in g:
+            grad_close(gk.reshape(g["grad." + key].shape), g["grad." + key] + corr[key], "grad " + key)
+            n += 1
+        elif ("gradrows." + key) in g:
+            ref = g["gradrows." + key]
+            full = gk.reshape(-1, ref.shape[1])
+            scale = float(g["gradnorm." + key]) / np.sqrt(full.size)       # rms entry of the full tensor
+            assert np.abs(full[:2] - (ref + corr[key][:2])).max() <= G_TIGHT * 100 * scale, "gradrows " + key
+            close(np.linalg.norm(full.astype(np.float64)), g["gradnorm." + key], atol=0, rtol=2e-3, what="gradnorm " + key)
+            n += 1
+        else:
+            assert not gk.any(), f"{key} must get a zero gradient"
+    assert n >= 26
+    net.sample_alpha, net.sample_rgb = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        rgbs_e, _, depth_e, _ = cfnerf_amd.render(H, W, focal, rays=T(g["rays"]).to(DEV), near=0., far=1., **kw_test)
+    close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth_e, g["depth_map_eval"], what="depth_map_eval")
 
 
 def test_three_steps_vs_reference_golden(golden):

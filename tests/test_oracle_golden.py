@@ -20,7 +20,7 @@ def close(a, b, atol=2e-6, rtol=2e-5, what=""):
 
 
 def cfg_from(g):
-    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]),
+    return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g.get("netdepth", 8)), n_flows=int(g.get("n_flows", 4)),
                        h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
 
 
@@ -324,6 +324,38 @@ def test_train_step_k16(golden):
             close(grads[k], ref, atol=2e-4 * scale, rtol=1e-3, what="grad " + k)
             n += 1
     assert n >= 30
+
+
+def test_train_step_wide_config(golden):
+    """G17: netwidth 192, netdepth 6, n_flows 3, h_alpha 96, h_rgb 96 - the oracle against the real reference outside the shipped configs"""
+    g = golden("g17_train_wide_config")
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    assert list(O.param_shapes(cfg).keys()) == [k for k in g["state_dict_keys"] if "idx" not in k and "mask" not in k]
+    rays = T(g["rays"])
+    packed = O.pack_rays(int(g["H"]), int(g["W"]), float(g["focal"]), rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret = O.train_step(p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    close(ret["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(ret["raw"][:2], g["raw_first2"], atol=5e-6, rtol=5e-5, what="raw")
+    close(scal["loss"], g["loss"], rtol=2e-5, what="loss")
+    close(scal["loss_entropy"], g["loss_entropy"], atol=2e-6, rtol=2e-5, what="entropy")
+    n = 0
+    for k in p:
+        if ("grad." + k) in g:
+            ref = g["grad." + k]
+            close(grads[k], ref, atol=2e-4 * max(1e-7, float(np.abs(ref).max())), rtol=1e-3, what="grad " + k)
+            n += 1
+        elif ("gradrows." + k) in g:
+            ref = g["gradrows." + k]
+            close(grads[k][:2], ref, atol=2e-4 * max(1e-7, float(np.abs(ref).max())), rtol=1e-3, what="gradrows " + k)
+            close(grads[k].double().norm(), g["gradnorm." + k], atol=0, rtol=1e-4, what="gradnorm " + k)
+            n += 1
+    assert n >= 26
+    ea, er = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    ea[-1] = 0
+    er[-1] = 0
+    e = O.render_rays(p, packed, cfg, ea, er, False)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")
 
 
 def _manifest():
