@@ -538,6 +538,37 @@ def main():
             g17["grad." + k] = v.grad.clone()
     out["g17_train_wide_config"] = g17
 
+    # ---------------- G18: train step at K = 100 latent samples (above the reference's default of 64, RUN:631; the build accepts up to
+    #                  128 and runs the flow phase on the hardware transcendentals from K = 16 on) --------------------------------------
+    rng18 = np.random.default_rng(118)
+    cfg = O.OracleCfg(netwidth=64, K_samples=100)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 66, tmp, K_samples=100)
+    n = 4
+    rays, (H, W, focal) = fern_rays(rng18, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng18.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    t_rand = torch.tensor(rng18.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng18.standard_normal((100, 1)), dtype=torch.float32)
+    er = torch.tensor(rng18.standard_normal((100, 3)), dtype=torch.float32)
+    with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
+    nk, eps, beta1 = 100, 1e-05, 0.01
+    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    g18 = dict(seed=66, netwidth=64, K=100, H=H, W=W, focal=focal, rays=rays_t, target=target, t_rand=t_rand, eps_alpha=ea, eps_rgb=er,
+               beta1=beta1, rgb_map=rgbs, depth_map=depth, raw_first1=extras["raw"][:1], loss=loss.detach(), loss_nll=loss_nll.detach(),
+               loss_entropy=extras["loss_entropy"].mean().detach())
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            g18["grad." + k[len("module."):]] = v.grad.clone()
+    out["g18_train_k100"] = g18
+
     import hashlib
     import json
     argv = sys.argv[1:]

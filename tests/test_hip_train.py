@@ -174,9 +174,11 @@ def test_gradients_with_n_flows_other_than_four_vs_oracle(F, W, K, N):
     close(rgb2, r2["rgb_map"], what="rgb_map after one step")
 
 
-def test_train_step_k16_vs_reference_golden(golden):
-    """G16: loss and every parameter gradient of the REAL reference at K = 16 latent samples."""
-    g = golden("g16_train_k16")
+@pytest.mark.parametrize("fixture", ["g16_train_k16", "g18_train_k100"])
+def test_train_step_k16_vs_reference_golden(golden, fixture):
+    """G16 / G18: loss and every parameter gradient of the REAL reference at K = 16 latent samples (BASELINE config 4) and at K = 100
+    (above the reference's default of 64): both run the flow phase on the hardware transcendentals."""
+    g = golden(fixture)
     cfg = cfg_from(g)
     _, kw_train, _, model, p, _ = build_model(cfg, int(g["seed"]))
     net = model.module

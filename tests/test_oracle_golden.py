@@ -306,9 +306,10 @@ def test_adam_on_the_references_own_gradients(golden):
         lr = float(g[f"lr_after{step}"])
 
 
-def test_train_step_k16(golden):
-    """G16: loss and every gradient at K = 16 latent samples (BASELINE config 4's count)."""
-    g = golden("g16_train_k16")
+@pytest.mark.parametrize("fixture", ["g16_train_k16", "g18_train_k100"])
+def test_train_step_k16(golden, fixture):
+    """G16 / G18: loss and every gradient at K = 16 latent samples (BASELINE config 4's count) and at K = 100."""
+    g = golden(fixture)
     cfg = cfg_from(g)
     p = O.make_params(cfg, int(g["seed"]))
     rays = T(g["rays"])
