@@ -270,3 +270,15 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     assert n_big <= max(n_cu, nt), (n_big, n_cu)
     if P >= 512 * 64:
         assert n_big >= n_cu - 8, (n_big, n_cu)            # enough points: the launch fills the chip
+
+
+def test_bench_gpus_n_without_enough_gpus_fails_cleanly():
+    """`python bench.py --gpus N` with no launcher above it starts its own ranks; where fewer than N GPUs are visible it must say so and
+    exit non-zero BEFORE anything touches a GPU (here: none or one visible), not die inside a rank."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CFNERF_BENCH_SAME_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--gpus", "64"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "--gpus 64" in r.stderr and "CFNERF_BENCH_SAME_GPU" in r.stderr and r.stdout.strip() == ""
