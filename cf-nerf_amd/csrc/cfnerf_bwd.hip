@@ -641,12 +641,26 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
             __syncthreads();
         }
         // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
+#ifdef CFN_NO_BPRE      // (A/B builds)
+        constexpr bool kBPre = false;
+#else
+        // the next layer's first weight fragments cross L2 under this layer's epilogue: -7 .. -13 us per launch at W = 256; at W = 512 the 16
+        // extra registers cost more than the latency (+25 us), so the wide kernels fetch them at the top of the k-loop as before
+        constexpr bool kBPre = PREC == PREC_F32 && W <= 256;
+#endif
+        f32x4 bpre[NTW];
+        if (kBPre) b_prefetch<NTW>(T.bt_trunk[D - 1], wave, kWaves, wp, bpre);
         for (int l = D - 1; l >= 1; --l) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
-            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
+            if (kBPre) {
+                mma_seg_pre<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD, bpre);
+                if (l > 1) b_prefetch<NTW>(T.bt_trunk[l - 1], wave, kWaves, wp, bpre);
+            } else {
+                mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
+            }
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             __syncthreads();

@@ -80,14 +80,14 @@ __device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NTW], const f32x4 a0,
 // register copies are needed.  The packed operand is read through ONE buffer descriptor over the packed-weight array: a
 // lane keeps a single byte offset (16 * lane) for every n-tile and k-chunk, what differs is a SCALAR offset (so[j] + 1 KB per
 // chunk) - no 64-bit vector address arithmetic between the MFMAs (it came out of their issue slots: 4 of the loop's 6 VALU).
-template <int NTW, int NV>
+template <int NTW, int NV, bool PRE = false>
 __device__ __forceinline__ void mma_loop(f32x16 (&acc)[2][NTW], const __amdgpu_buffer_rsrc_t wr, const int voff, const int (&so)[NTW],
-                                         const float* a_ptr, int lda, int KC) {
+                                         const float* a_ptr, int lda, int KC, const f32x4* bpre = nullptr) {
     f32x4 bA[NTW], bB[NTW], a0A, a1A, a0B, a1B;
     auto bload = [&](int j, int kc) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, so[j] + kc * 1024, 0)); };
     CFN_SETPRIO(CFN_MMA_PRIO);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) bA[j] = bload(j, 0);
+    for (int j = 0; j < NV; ++j) bA[j] = PRE ? bpre[j] : bload(j, 0);      // PRE: chunk 0 was fetched ahead, under the previous layer's epilogue
     a0A = *reinterpret_cast<const f32x4*>(a_ptr);
     a1A = *reinterpret_cast<const f32x4*>(a_ptr + 32 * lda);
     int kc = 0;
@@ -135,6 +135,41 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[2][NTW], const SubL s, int
     // accumulators stay in place (a set of partial variants made the compiler shuffle 32 accumulator registers through
     // v_mov_b64 around every GEMM segment).
     mma_loop<NTW, NTW>(acc, wr, lane * 16, so, a_ptr, lda, KC);
+}
+
+// The first B fragments (k-chunk 0) of a dense block, fetched AHEAD of it: issued before the barrier / epilogue that precedes the
+// block, they cross L2 while that runs, and mma_seg_pre starts its first MFMAs without waiting for them.
+template <int NTW>
+__device__ __forceinline__ void b_prefetch(const SubL s, int nt0, int nts, const float* __restrict__ wp, f32x4 (&bpre)[NTW]) {
+    const int lane = lane_id_opaque();
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) nt = nt0 < (int)s.nt ? nt0 : 0;
+        const int so = __builtin_amdgcn_readfirstlane((int)((s.w_off + (unsigned)nt * s.kc * 256u) * 4u));
+        bpre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, so, 0));
+    }
+}
+template <int NTW>
+__device__ __forceinline__ void mma_seg_pre(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const float* __restrict__ wp,
+                                            const float* lds_a, int lda, const f32x4 (&bpre)[NTW]) {
+    const int lane = lane_id_opaque();
+    const int KC = s.kc;
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
+    if (nvalid == 0) return;
+    const float* a_ptr = lds_a + (lane & 31) * lda + 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7ffffff0, 0x00020000);
+    int so[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) nt = nt0;
+        so[j] = __builtin_amdgcn_readfirstlane((int)((s.w_off + (unsigned)nt * KC * 256u) * 4u));
+    }
+    mma_loop<NTW, NTW, true>(acc, wr, lane * 16, so, a_ptr, lda, KC, bpre);
 }
 
 // ================= opt-in split-bf16 ("bf16x3") operand path =====================================
