@@ -644,8 +644,9 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
 #ifdef CFN_NO_BPRE      // (A/B builds)
         constexpr bool kBPre = false;
 #else
-        // the next layer's first weight fragments cross L2 under this layer's epilogue: -7 .. -13 us per launch at W = 256; at W = 512 the 16
-        // extra registers cost more than the latency (+25 us), so the wide kernels fetch them at the top of the k-loop as before
+        // the next layer's first weight fragments cross L2 under this layer's epilogue: -7 .. -13 us per launch at W = 256 on one box, +-0 on
+        // another (the co-resident workgroup already covers most of that latency); at W = 512 the 16 extra registers cost +25 us, so the wide
+        // kernels fetch them at the top of the k-loop as before.  (The same in the forward's trunk: +-0 on both boxes, not kept.)
         constexpr bool kBPre = PREC == PREC_F32 && W <= 256;
 #endif
         f32x4 bpre[NTW];
