@@ -41,6 +41,36 @@ def row_shard(H: int, rank: int, world: int):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
+def gather_rows(local: dict, H: int, world: int, rank: int, group=None, dst: int = 0):
+    """The optional exchange of the row-tiled evaluation: every rank rendered rows ``row_shard(H, rank, world)`` of one
+    image with ``render_uncertainty``; rank ``dst`` gets the full-image maps (``rgb_mean [H,W,3]``, ``rgb_unc``, ``disp_mean``,
+    ``depth_mean``, and ``sq_err`` when present), the others ``None``.  32 B per pixel travel (20 MB for 800 x 800), once per image;
+    the render itself needs no exchange.  Shards differ by at most one row: they are padded to the largest for ``all_gather``.
+    A gloo group (CPU tests, ranks sharing one GPU) is served through host copies."""
+    import torch.distributed as dist
+    keys = [k for k in ("rgb_mean", "rgb_unc", "disp_mean", "depth_mean", "sq_err") if k in local]
+    hmax = max(row_shard(H, r, world)[1] - row_shard(H, r, world)[0] for r in range(world))
+    via_host = dist.get_backend(group) == "gloo"
+    out = {}
+    for k in keys:
+        t = local[k].contiguous()
+        dev = t.device
+        if via_host:
+            t = t.cpu()
+        pad = torch.zeros((hmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        if rank == dst:
+            rows = [parts[r][:row_shard(H, r, world)[1] - row_shard(H, r, world)[0]] for r in range(world)]
+            out[k] = torch.cat(rows, 0).to(dev)
+    if rank != dst:
+        return None
+    if "sq_err" in out:
+        out["mse"] = out["sq_err"].mean()
+    return out
+
+
 @torch.no_grad()
 def render_uncertainty(H, W, focal, c2w, network_fn, near=0., far=1., ndc=True, lindisp=False, white_bkgd=False,
                        rows=None, want_maps=False, t_vals=None, gt=None, **_ignored):

@@ -94,3 +94,41 @@ def test_shard_bounds_and_lr_schedule():
     assert abs(TR.lr_at(5e-4, 250, 0, 250001) - 5e-5) < 1e-12
     for s in (0, 10, 1000):
         assert abs(TR.lr_at(5e-4, 250, 100, s + 1) - O.lr_schedule(5e-4, 250, 100 + s)) < 1e-15
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cfnerf_amd import evaluate as E
+    H, W = 7, 5                                      # 7 rows over 2 ranks: shards of 4 and 3 rows
+    full = {"rgb_mean": torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3), "rgb_unc": torch.ones(H, W, 3) * 0.5,
+            "disp_mean": torch.arange(H * W, dtype=torch.float32).reshape(H, W), "depth_mean": -torch.arange(H * W, dtype=torch.float32).reshape(H, W),
+            "sq_err": torch.full((H, W, 3), 0.25)}
+    r0, r1 = E.row_shard(H, rank, world)
+    got = E.gather_rows({k: v[r0:r1].clone() for k, v in full.items()}, H, world, rank)
+    if rank == 0:
+        q.put({k: (v.numpy() if torch.is_tensor(v) and v.ndim else float(v)) for k, v in got.items()})
+    else:
+        assert got is None
+    dist.destroy_process_group()
+
+
+def test_row_tiled_evaluation_gathers_the_full_image_on_rank_0():
+    """image rows tiled across ranks with no exchange for the render; the optional gather of the fused maps to rank 0"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    H, W = 7, 5
+    np.testing.assert_array_equal(got["rgb_mean"], np.arange(H * W * 3, dtype=np.float32).reshape(H, W, 3))
+    np.testing.assert_array_equal(got["disp_mean"], np.arange(H * W, dtype=np.float32).reshape(H, W))
+    np.testing.assert_array_equal(got["depth_mean"], -np.arange(H * W, dtype=np.float32).reshape(H, W))
+    assert got["rgb_unc"].shape == (H, W, 3) and abs(got["mse"] - 0.25) < 1e-7
