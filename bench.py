@@ -466,9 +466,9 @@ def main():
         # its own roofline: three bf16 MFMAs per fp32 product on the 2.5 PFLOP/s dense bf16 matrix pipe
         alt["roofline"] = {"bound": "mfma (bf16 pipe, 3 MFMAs per fp32 product)", "peak": 2500.0 / 3, "unit": "fp32-equivalent TFLOP/s",
                            "achieved": alt["fwd_fp32_equiv_tflops"], "frac": alt["fwd_fp32_equiv_tflops"] / (2500.0 / 3),
-                           "note": "PMC: the matrix pipe is 34-40 % busy in this mode; the bf16 MFMA does not co-issue with other vector "
+                           "note": "PMC: the matrix pipe is 33-42 % busy in this mode; the bf16 MFMA does not co-issue with other vector "
                                    "instructions either and the mode carries 2.6x as many of them (hi/lo splits, v_perm de-interleaves) "
-                                   "as the fp32 path (profiles/r02_pmc_summary.txt section pmc_b16, DESIGN.md section 3)"}
+                                   "as the fp32 path (profiles/r03_pmc_summary.txt section pmc_b16, DESIGN.md section 3)"}
 
     # BASELINE config 4 (K = 16, 1024 rays per GPU) next to the line when the job spans several GPUs (default run only)
     cfg4 = None
