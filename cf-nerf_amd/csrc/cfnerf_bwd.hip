@@ -111,9 +111,13 @@ __device__ __forceinline__ float t_sigmoid(float x) { return t_rcp(1.f + t_exp(-
 // ga / gz = d loss / d (alpha, rgb) flow outputs (activation and entropy-Jacobian terms already added), cE = the weight of the
 // log-det terms (- d_entropy / (P K)).  Accumulates d loss / d theta into gth and the base-Gaussian terms into gms.  Shared by
 // the fused tail kernel and the unfused flows_bwd_kernel, so both differentiate with the same arithmetic.
-__device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth)[84], float (&gms)[8], const f32x4 e, const float a_mean,
+template <class GACC>
+__device__ __forceinline__ void flows_adjoint(const float (&th)[84], GACC& gth, float (&gms)[8], const f32x4 e, const float a_mean,
                                               const float a_std, const float (&r_mean)[3], const float (&r_std)[3], float ga, float (&gz)[3],
                                               const float cE, const bool valid) {
+#pragma clang fp contract(fast)      // gradient arithmetic: a*b + c may fuse (the library is built with -ffp-contract=off for the FORWARD's
+                                     // parity with torch's separate ops; the backward has no such constraint and fused pairs halve its
+                                     // multiply / add instruction count)
     // ---- recompute the flows, keeping each step's input and tanh
     float zin[4][3], tt[4][3], ain[4], ta[4];
     float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};
@@ -148,8 +152,8 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth
         float gt0 = d1_0 * gu0;
         float gt1 = th[(0 * 3 + 1) * 4 + f] * gu0 + d1_1 * gu1;
         float gt2 = th[(0 * 3 + 2) * 4 + f] * gu0 + th[(1 * 3 + 2) * 4 + f] * gu1 + d1_2 * gu2;
-        gth[36 + f] += gu0 * t0; gth[40 + f] += gu1 * t1; gth[44 + f] += gu2 * t2;
-        gth[(0 * 3 + 1) * 4 + f] += gu0 * t1; gth[(0 * 3 + 2) * 4 + f] += gu0 * t2; gth[(1 * 3 + 2) * 4 + f] += gu1 * t2;
+        gth.add(36 + f, gu0 * t0); gth.add(40 + f, gu1 * t1); gth.add(44 + f, gu2 * t2);
+        gth.add((0 * 3 + 1) * 4 + f, gu0 * t1); gth.add((0 * 3 + 2) * 4 + f, gu0 * t2); gth.add((1 * 3 + 2) * 4 + f, gu1 * t2);
         // log-det: ld_i = log(|q_i| + 1e-8), q_i = (1 - t_i^2) d1_i d2_i + 1     (FLW:251-259)
         if (cE != 0.f && valid) {
             const float q0 = (1.f - t0 * t0) * (d1_0 * d2_0) + 1.f, q1 = (1.f - t1 * t1) * (d1_1 * d2_1) + 1.f,
@@ -157,14 +161,14 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth
             const float gq0 = cE * copysignf(1.f, q0) * t_rcp(fabsf(q0) + 1e-08f), gq1 = cE * copysignf(1.f, q1) * t_rcp(fabsf(q1) + 1e-08f),
                         gq2 = cE * copysignf(1.f, q2) * t_rcp(fabsf(q2) + 1e-08f);
             gt0 += gq0 * (-2.f * t0 * d1_0 * d2_0); gt1 += gq1 * (-2.f * t1 * d1_1 * d2_1); gt2 += gq2 * (-2.f * t2 * d1_2 * d2_2);
-            gth[36 + f] += gq0 * (1.f - t0 * t0) * d2_0; gth[40 + f] += gq1 * (1.f - t1 * t1) * d2_1; gth[44 + f] += gq2 * (1.f - t2 * t2) * d2_2;
-            gth[48 + f] += gq0 * (1.f - t0 * t0) * d1_0; gth[52 + f] += gq1 * (1.f - t1 * t1) * d1_1; gth[56 + f] += gq2 * (1.f - t2 * t2) * d1_2;
+            gth.add(36 + f, gq0 * (1.f - t0 * t0) * d2_0); gth.add(40 + f, gq1 * (1.f - t1 * t1) * d2_1); gth.add(44 + f, gq2 * (1.f - t2 * t2) * d2_2);
+            gth.add(48 + f, gq0 * (1.f - t0 * t0) * d1_0); gth.add(52 + f, gq1 * (1.f - t1 * t1) * d1_1); gth.add(56 + f, gq2 * (1.f - t2 * t2) * d1_2);
         }
         const float gp0 = gt0 * (1.f - t0 * t0), gp1 = gt1 * (1.f - t1 * t1), gp2 = gt2 * (1.f - t2 * t2);
-        gth[60 + f] += gp0; gth[64 + f] += gp1; gth[68 + f] += gp2;                         // b
+        gth.add(60 + f, gp0); gth.add(64 + f, gp1); gth.add(68 + f, gp2);                         // b
         // pre_i = sum_{j>=i} R2[i][j] zp_j,  R2[i][i] = d2_i,  R2[i][j>i] = D[j][i]
-        gth[48 + f] += gp0 * zp0; gth[52 + f] += gp1 * zp1; gth[56 + f] += gp2 * zp2;
-        gth[(1 * 3 + 0) * 4 + f] += gp0 * zp1; gth[(2 * 3 + 0) * 4 + f] += gp0 * zp2; gth[(2 * 3 + 1) * 4 + f] += gp1 * zp2;
+        gth.add(48 + f, gp0 * zp0); gth.add(52 + f, gp1 * zp1); gth.add(56 + f, gp2 * zp2);
+        gth.add((1 * 3 + 0) * 4 + f, gp0 * zp1); gth.add((2 * 3 + 0) * 4 + f, gp0 * zp2); gth.add((2 * 3 + 1) * 4 + f, gp1 * zp2);
         const float gzp0 = d2_0 * gp0;
         const float gzp1 = th[(1 * 3 + 0) * 4 + f] * gp0 + d2_1 * gp1;
         const float gzp2 = th[(2 * 3 + 0) * 4 + f] * gp0 + th[(2 * 3 + 1) * 4 + f] * gp1 + d2_2 * gp2;
@@ -173,17 +177,17 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth
         {
             const float d1 = th[72 + f], d2 = th[76 + f], tav = ta[f], ai = ain[f];
             float gta = ga * d1;
-            gth[72 + f] += ga * tav;
+            gth.add(72 + f, ga * tav);
             if (cE != 0.f && valid) {
                 const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;
                 const float gq = cE * copysignf(1.f, q) * t_rcp(fabsf(q) + 1e-08f);
                 gta += gq * (-2.f * tav * d1 * d2);
-                gth[72 + f] += gq * (1.f - tav * tav) * d2;
-                gth[76 + f] += gq * (1.f - tav * tav) * d1;
+                gth.add(72 + f, gq * (1.f - tav * tav) * d2);
+                gth.add(76 + f, gq * (1.f - tav * tav) * d1);
             }
             const float gpa = gta * (1.f - tav * tav);
-            gth[80 + f] += gpa;
-            gth[76 + f] += gpa * ai;
+            gth.add(80 + f, gpa);
+            gth.add(76 + f, gpa * ai);
             ga += gpa * d2;
         }
     }
@@ -193,29 +197,43 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], float (&gth
     gms[5] += gz[0] * e[0]; gms[6] += gz[1] * e[1]; gms[7] += gz[2] * e[2];
 }
 
+// Where the adjoint accumulates d loss / d theta of the current point over the latent samples: 84 registers per lane.
+// (Round 3 tried LDS instead - one float per (entry, wave, lane), accumulated with ds_add_f32, to take 84 registers and the ~500
+// v_mov / v_accvgpr moves they cause per (chunk, latent) out of the fused tail kernel: the vector-instruction count fell from 1 329 to
+// 1 011, and the kernel took 333 us instead of 64 - LDS atomics run at a fraction of the plain LDS rate.  Not kept.)
+struct GReg {
+    float g[84];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 84; ++i) g[i] = 0.f;
+    }
+    __device__ __forceinline__ void add(int i, float v) { g[i] += v; }
+    __device__ __forceinline__ float get(int i) const { return g[i]; }
+};
 // One row of d loss / d theta (the pre-activation outputs of the flow-parameter heads), in the [P,128] layout of theta:
 // the diagonals were tanh-ed (MOD:341-348), the padding columns are written as zeros (the weight-gradient GEMM reads them).
-__device__ __forceinline__ void store_gtheta_row(float* __restrict__ row, const float (&th)[84], float (&gth)[84]) {
-#pragma unroll
-    for (int i = 36; i < 60; ++i) gth[i] *= (1.f - th[i] * th[i]);
-#pragma unroll
-    for (int i = 72; i < 80; ++i) gth[i] *= (1.f - th[i] * th[i]);
+template <class GACC>
+__device__ __forceinline__ void store_gtheta_row(float* __restrict__ row, const float (&th)[84], const GACC& gth) {
+    // element i of the row: the diagonals (36..59, 72..79) chain through their tanh
+    auto val = [&](int i) { const float g = gth.get(i); return ((i >= 36 && i < 60) || (i >= 72 && i < 80)) ? g * (1.f - th[i] * th[i]) : g; };
     f32x4* gp = reinterpret_cast<f32x4*>(row);
 #pragma unroll
-    for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = gth[q * 4]; v[1] = gth[q * 4 + 1]; v[2] = gth[q * 4 + 2]; v[3] = gth[q * 4 + 3]; gp[q] = v; }
+    for (int q = 0; q < 18; ++q) { f32x4 v; v[0] = val(q * 4); v[1] = val(q * 4 + 1); v[2] = val(q * 4 + 2); v[3] = val(q * 4 + 3); gp[q] = v; }
     f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
 #pragma unroll
     for (int q = 18; q < 24; ++q) gp[q] = zero;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { f32x4 v; v[0] = gth[72 + q * 4]; v[1] = gth[73 + q * 4]; v[2] = gth[74 + q * 4]; v[3] = gth[75 + q * 4]; gp[24 + q] = v; }
+    for (int q = 0; q < 3; ++q) { f32x4 v; v[0] = val(72 + q * 4); v[1] = val(73 + q * 4); v[2] = val(74 + q * 4); v[3] = val(75 + q * 4); gp[24 + q] = v; }
 #pragma unroll
     for (int q = 27; q < 32; ++q) gp[q] = zero;
 }
 
 __global__ __launch_bounds__(kThreads)
 void tail_bwd_kernel(const TailArgs A) {
+#pragma clang fp contract(fast)
     __shared__ float carry[kWaves][kMaxK];
     const int lane = lane_id_opaque(), wave = wave_id();
+    GReg gth;
     // one wave per (ray, k-part): a ray's K latent samples are independent up to the sums over k, which are left to the
     // consumers (bwd_data adds the partial g_theta's while loading them, reduce_gms adds the rows), so small batches and
     // large K still fill the chip (this kernel runs one wave per SIMD: ~360 registers)
@@ -243,7 +261,7 @@ void tail_bwd_kernel(const TailArgs A) {
         const int s = ch * 64 + lane;
         const bool valid = s < S;
         const int64_t p = ray * (int64_t)S + (valid ? s : 0);
-        float th[84], gth[84];
+        float th[84];
         {
             const f32x4* tp = reinterpret_cast<const f32x4*>(A.theta + p * kThetaAll);
 #pragma unroll
@@ -251,8 +269,7 @@ void tail_bwd_kernel(const TailArgs A) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) { const f32x4 v = tp[kThetaRgb / 4 + q]; th[72 + q * 4] = v[0]; th[73 + q * 4] = v[1]; th[74 + q * 4] = v[2]; th[75 + q * 4] = v[3]; }
         }
-#pragma unroll
-        for (int i = 0; i < 84; ++i) gth[i] = 0.f;
+        gth.clear();
         const float zv = A.z[p];
         const float dz = (s >= S - 1) ? 1e1f : A.z[p + 1] - zv;
         const float dist = dz * dnorm;
@@ -320,6 +337,7 @@ __global__ __launch_bounds__(kThreads)
 void flows_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ theta, const float* __restrict__ eps, const float* __restrict__ flat,
                       const float* __restrict__ d_raw, const float* __restrict__ d_ent, int64_t P, int K, float* __restrict__ g_theta,
                       float* __restrict__ gms_partials) {
+#pragma clang fp contract(fast)
     const int lane = lane_id_opaque(), wave = wave_id();
     const int64_t pi = (int64_t)blockIdx.x * kThreads + wave * 64 + lane;
     const bool valid = pi < P;
@@ -328,7 +346,8 @@ void flows_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ t
     const float a_mean = flat[0], a_std = flat[1];
     const float r_mean[3] = {flat[2], flat[3], flat[4]};
     const float r_std[3] = {flat[5], flat[6], flat[7]};
-    float th[84], gth[84], gms[8];
+    float th[84], gms[8];
+    GReg gth;
     {
         const f32x4* tp = reinterpret_cast<const f32x4*>(theta + p * kThetaAll);
 #pragma unroll
@@ -336,8 +355,7 @@ void flows_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ t
 #pragma unroll
         for (int q = 0; q < 3; ++q) { const f32x4 v = tp[kThetaRgb / 4 + q]; th[72 + q * 4] = v[0]; th[73 + q * 4] = v[1]; th[74 + q * 4] = v[2]; th[75 + q * 4] = v[3]; }
     }
-#pragma unroll
-    for (int i = 0; i < 84; ++i) gth[i] = 0.f;
+    gth.clear();
 #pragma unroll
     for (int i = 0; i < 8; ++i) gms[i] = 0.f;
     for (int k = 0; k < K; ++k) {
@@ -371,6 +389,7 @@ __global__ __launch_bounds__(kThreads)
 void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t N, int S,
                           int K, int white_bkgd, const float* __restrict__ d_rgb, const float* __restrict__ d_disp,
                           const float* __restrict__ d_depth, const float* __restrict__ d_weights, float* __restrict__ d_raw) {
+#pragma clang fp contract(fast)      // (like the fused tail kernel: the two must agree to rounding, see tests/test_hip_unfused_seam.py)
     __shared__ float carryT[kWaves][kCompMaxChunks];
     const int lane = lane_id_opaque(), wave = wave_id();
     const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
