@@ -299,12 +299,10 @@ void tail_bwd_kernel(const TailArgs A) {
             float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
             if (wb) g -= (G0 + G1 + G2);                                       // rgb_map += 1 - acc  (RUN:452)
             const float gw = valid ? g * w : 0.f;
-            const float incl = wave_scan_add_rev(gw);                          // sum over samples >= s of this chunk
             const float car = carry[wave][k];
-            float excl = __shfl_down(incl, 1, 64);                             // exclusive suffix WITHOUT a subtraction:
-            if (lane == 63) excl = 0.f;                                        // it is later divided by ~1e-10 for opaque samples
+            float excl, tot;
+            comp_suffix(gw, excl, tot);                                        // sum over the samples above s of this chunk, and the chunk's total
             const float suffix = excl + car;                                   // sum over samples > s of the ray
-            const float tot = __shfl(incl, 0, 64);
             if (lane == 0) carry[wave][k] = car + tot;
             const float xk = (1.f - alpha) + 1e-10f;                           // cumprod factor of RUN:443
             const float dalpha = g * Tt - suffix * t_rcp(xk);
@@ -410,13 +408,13 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                 const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
                 alpha = 1.f - expf(-softplus_f(raw[((ray * S + s) * (int64_t)K + k) * 4 + 3]) * (dz * dnorm));
             }
-            const float incl = wave_scan_mul((1.f - alpha) + 1e-10f);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) { excl = 1.f; carryT[wave][ch] = car; }
+            float incl, excl;
+            comp_scan_mul((1.f - alpha) + 1e-10f, incl, excl);
+            if (lane == 0) carryT[wave][ch] = car;
             const float wgt = alpha * (car * excl);
-            ad += wave_sum(wgt * zv);
-            aa += wave_sum(wgt);
-            car *= __shfl(incl, 63, 64);
+            ad += comp_sum(wgt * zv);
+            aa += comp_sum(wgt);
+            car *= comp_last(incl);
         }
         const float G0 = d_rgb[ray * 3 * (int64_t)K + 0 * K + k], G1 = d_rgb[ray * 3 * (int64_t)K + 1 * K + k], G2 = d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
         float Gd = (d_depth != nullptr) ? d_depth[ray * (int64_t)K + k] : 0.f;
@@ -445,9 +443,8 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                 alpha = 1.f - expf(-softplus_f(rv[3]) * dist);
             }
             const float xk = (1.f - alpha) + 1e-10f;
-            const float incl_m = wave_scan_mul(xk);
-            float excl_m = __shfl_up(incl_m, 1, 64);
-            if (lane == 0) excl_m = 1.f;
+            float incl_m, excl_m;
+            comp_scan_mul(xk, incl_m, excl_m);
             const float Tt = carryT[wave][ch] * excl_m;
             const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
             const float w = alpha * Tt;
@@ -455,11 +452,10 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
             g += Ga;
             if (d_weights != nullptr && valid) g += d_weights[idx];
             const float gw = valid ? g * w : 0.f;
-            const float incl = wave_scan_add_rev(gw);
-            float excl = __shfl_down(incl, 1, 64);
-            if (lane == 63) excl = 0.f;
+            float excl, tot;
+            comp_suffix(gw, excl, tot);
             const float suffix = excl + sufcar;
-            sufcar += __shfl(incl, 0, 64);
+            sufcar += tot;
             const float dalpha = g * Tt - suffix * t_rcp(xk);
             const float sg = t_sigmoid(rv[3]);                                 // softplus'
             if (valid) {

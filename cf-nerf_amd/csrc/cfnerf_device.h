@@ -537,6 +537,67 @@ __device__ __forceinline__ float wave_scan_add_rev(float v) {
     return v;
 }
 
+// ---- the same scans / reductions on DPP (data-parallel primitives: the cross-lane move is a modifier of a vector-ALU instruction,
+// no LDS round trip).  __shfl_* compile to ds_bpermute_b32 - an LDS instruction with ~100 cycles of latency - and a scan is a chain
+// of six of them; the gfx9 DPP scan is row_shr:1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 to carry the
+// row totals on (the sequence LLVM's own wave scan uses).  A lane without a source keeps `identity` (bound_ctrl off).
+#ifdef CFN_NO_DPP           // (A/B builds: the shuffle forms everywhere)
+constexpr bool kUseDpp = false;
+#else
+constexpr bool kUseDpp = true;
+#endif
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float identity, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_scan_add_dpp(float v) {          // inclusive prefix sum over the 64 lanes
+    v += dpp_mov<0x111, 0xf, 0xf>(0.f, v);
+    v += dpp_mov<0x112, 0xf, 0xf>(0.f, v);
+    v += dpp_mov<0x114, 0xf, 0xf>(0.f, v);
+    v += dpp_mov<0x118, 0xf, 0xf>(0.f, v);
+    v += dpp_mov<0x142, 0xa, 0xf>(0.f, v);                              // row_bcast:15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xc, 0xf>(0.f, v);                              // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul_dpp(float v) {          // inclusive prefix product
+    v *= dpp_mov<0x111, 0xf, 0xf>(1.f, v);
+    v *= dpp_mov<0x112, 0xf, 0xf>(1.f, v);
+    v *= dpp_mov<0x114, 0xf, 0xf>(1.f, v);
+    v *= dpp_mov<0x118, 0xf, 0xf>(1.f, v);
+    v *= dpp_mov<0x142, 0xa, 0xf>(1.f, v);
+    v *= dpp_mov<0x143, 0xc, 0xf>(1.f, v);
+    return v;
+}
+// value of the previous lane (lane 0: `identity`): wave_shr:1
+__device__ __forceinline__ float wave_prev_dpp(float v, float identity) { return dpp_mov<0x138, 0xf, 0xf>(identity, v); }
+__device__ __forceinline__ float wave_last(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_last(wave_scan_add_dpp(v)); }     // (same in every lane: an SGPR)
+
+// The cross-lane steps of the composite and of its adjoint, in ONE place: the fused forward / tail kernels and the standalone
+// composite_kernel / composite_bwd_kernel must use the same arithmetic (the unfused seam's gradients are held to the fused path's to 1e-6).
+__device__ __forceinline__ void comp_scan_mul(float xk, float& incl, float& excl) {     // inclusive / exclusive running product over the lanes
+    if (kUseDpp) { incl = wave_scan_mul_dpp(xk); excl = wave_prev_dpp(incl, 1.f); }
+    else { incl = wave_scan_mul(xk); excl = __shfl_up(incl, 1, 64); if (lane_id() == 0) excl = 1.f; }
+}
+__device__ __forceinline__ float comp_sum(float x) { return kUseDpp ? wave_sum_dpp(x) : wave_sum(x); }
+__device__ __forceinline__ float comp_last(float incl) { return kUseDpp ? wave_last(incl) : __shfl(incl, 63, 64); }
+// exclusive suffix sum (lanes ABOVE this one) and the total, without a subtraction (the suffix is later divided by ~1e-10 for opaque samples)
+__device__ __forceinline__ void comp_suffix(float gw, float& excl, float& tot) {
+    const int lane = lane_id();
+    if (kUseDpp) {
+        // reverse the lane order (one LDS permute), prefix-scan on DPP, shift by one lane, permute back: 2 LDS round trips, not 8
+        const float rev = __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) * 4, __float_as_int(gw)));
+        const float incl_r = wave_scan_add_dpp(rev);
+        tot = wave_last(incl_r);
+        excl = __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) * 4, __float_as_int(wave_prev_dpp(incl_r, 0.f))));
+    } else {
+        const float incl = wave_scan_add_rev(gw);
+        excl = __shfl_down(incl, 1, 64);
+        if (lane == 63) excl = 0.f;
+        tot = __shfl(incl, 0, 64);
+    }
+}
+
 // gamma(v): channel c of the encoding of a 3-vector (HLP:42-51): c<3 identity, then per
 // frequency f: sin(2^f v) x3, cos(2^f v) x3.  2^f * v is exact in fp32.
 __device__ __forceinline__ float enc_channel(const float* v, int c) {

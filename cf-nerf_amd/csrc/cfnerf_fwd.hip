@@ -455,9 +455,8 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                         if (MODE == 0) {
                             const float alpha = valid ? 1.f - M::exp(-sp_a * dist) : 0.f;                // RUN:424,442
                             const float xk = (1.f - alpha) + 1e-10f;                                   // RUN:443
-                            const float incl = wave_scan_mul(xk);
-                            float excl = __shfl_up(incl, 1, 64);
-                            if (lane == 0) excl = 1.f;
+                            float incl, excl;
+                            comp_scan_mul(xk, incl, excl);
                             float* cp = comp + k * 8;
                             const float Tcar = cp[5];
                             const float wgt = alpha * (Tcar * excl);
@@ -466,12 +465,12 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                                 f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
                                 *reinterpret_cast<f32x2*>(A.st_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
                             }
-                            const float s0 = wave_sum(wgt * M::sigmoid(z[0]));                          // RUN:431,444
-                            const float s1 = wave_sum(wgt * M::sigmoid(z[1]));
-                            const float s2 = wave_sum(wgt * M::sigmoid(z[2]));
-                            const float sd = wave_sum(wgt * zval);                                     // RUN:447
-                            const float sa = wave_sum(wgt);                                            // RUN:449
-                            const float tot = __shfl(incl, 63, 64);
+                            const float s0 = comp_sum(wgt * M::sigmoid(z[0]));                         // RUN:431,444
+                            const float s1 = comp_sum(wgt * M::sigmoid(z[1]));
+                            const float s2 = comp_sum(wgt * M::sigmoid(z[2]));
+                            const float sd = comp_sum(wgt * zval);                                     // RUN:447
+                            const float sa = comp_sum(wgt);                                            // RUN:449
+                            const float tot = comp_last(incl);
                             if (lane == 0) {
                                 cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar * tot;
                             }
@@ -609,17 +608,16 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
             }
             const float alpha = valid ? 1.f - expf(-softplus_f(rv[3]) * dist) : 0.f;
             const float xk = (1.f - alpha) + 1e-10f;
-            const float incl = wave_scan_mul(xk);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.f;
+            float incl, excl;
+            comp_scan_mul(xk, incl, excl);
             const float wgt = alpha * (car * excl);
             if (weights != nullptr && valid) weights[(ray * S + s) * (int64_t)K + k] = wgt;
-            a0 += wave_sum(wgt * sigmoid_f(rv[0]));
-            a1 += wave_sum(wgt * sigmoid_f(rv[1]));
-            a2 += wave_sum(wgt * sigmoid_f(rv[2]));
-            ad += wave_sum(wgt * zv);
-            aa += wave_sum(wgt);
-            car *= __shfl(incl, 63, 64);
+            a0 += comp_sum(wgt * sigmoid_f(rv[0]));
+            a1 += comp_sum(wgt * sigmoid_f(rv[1]));
+            a2 += comp_sum(wgt * sigmoid_f(rv[2]));
+            ad += comp_sum(wgt * zv);
+            aa += comp_sum(wgt);
+            car *= comp_last(incl);
         }
         if (lane == 0) {
             if (white_bkgd) { a0 = a0 + (1.f - aa); a1 = a1 + (1.f - aa); a2 = a2 + (1.f - aa); }
