@@ -10,6 +10,7 @@ cfg = O.OracleCfg(netwidth=256, K_samples=4)
 _, kw_train, kw_test, model, _, _ = build_model(cfg, 0)
 rays, (H, W, focal) = fern_rays(np.random.default_rng(0), 1024)
 rays = rays.cuda()
+if os.environ.get("TL_PREC"): model.module.set_precision(os.environ["TL_PREC"])
 TRAIN = os.environ.get("TL_MODE", "eval") == "train"
 if TRAIN:
     from cfnerf_amd import train as TR
@@ -34,3 +35,20 @@ lay = np.diff(np.concatenate([[t[1]], t[2:42]])).reshape(8, 5)
 print("per layer [wait, mfma(wave0), barrier1 wait, store(wave0), barrier2 wait] us:")
 print(np.round(lay, 2))
 print("mean", np.round(lay[1:].mean(0), 2))
+
+# every recorded tile of the two sampled workgroups (47 marks per tile with CFN_TIMESTAMP_FINE and D = 8):
+# [sampling, encode, sum over layers of (wait, mfma wave0, barrier1, store wave0, barrier2), heads, views, h_rgb, theta, flows] in us
+for sel in range(2):
+    mk = m[2048 + sel * 700: 2048 + (sel + 1) * 700].astype(np.float64)
+    n = int((mk > 0).sum())
+    mk = mk[:n] / 100.0
+    print("workgroup", sel, "marks", n)
+    prev_end = None
+    for t0 in range(0, n - 46, 47):
+        q = mk[t0:t0 + 47]
+        lay = np.diff(q[1:42]).reshape(8, 5)
+        rest = np.diff(q[41:47])
+        gap = (q[0] - prev_end) if prev_end is not None else 0.0
+        prev_end = q[46]
+        print("  tile", t0 // 47, "samp+gap %.1f" % gap, "enc %.1f" % (q[1] - q[0]), "layers[wait mfma b1 store b2]", np.round(lay.sum(0), 1),
+              "heads views hrgb theta flows", np.round(rest, 1), "total %.1f" % (q[46] - q[0] + gap))
