@@ -136,6 +136,120 @@ def fern_rays(rng, n, H=378, W=504, focal=407.5658):
     return np.stack([rays_o, rays_d], 0), (H, W, focal)
 
 
+G19 = dict(H=24, W=32, focal=36.0, near=2.0, far=6.0, n_views=20, i_test=(2, 10, 18), n_rand=128, n_steps=120, every=40,
+           netwidth=64, K=4, seed=65, scene_seed=1190, step_seed=1191, lrate=5e-4, lrate_decay=250, beta1=0.01)
+
+
+def g19_scene(seed, H, W, focal, near, far, n_views, n_blobs=6, n_quad=256):
+    """Analytic emissive-absorbing Gaussian blobs rendered by dense fp64 quadrature into `n_views` views on a sphere (the small
+    CPU twin of tools/procedural_scene.py: same construction, numpy / torch-CPU only)."""
+    rng = np.random.default_rng(seed)
+    c = torch.tensor(rng.uniform(-0.8, 0.8, (n_blobs, 3)))
+    sg = torch.tensor(rng.uniform(0.25, 0.45, n_blobs))
+    amp = torch.tensor(rng.uniform(3.0, 8.0, n_blobs))
+    col = torch.tensor(rng.uniform(0.1, 1.0, (n_blobs, 3)))
+    poses, images = [], []
+    for i, th in enumerate(np.linspace(-60, 60, n_views)):
+        th_r, ph_r = np.deg2rad(th), np.deg2rad(-20.0 - 10.0 * (i % 3))
+        trans = np.eye(4); trans[2, 3] = 4.0
+        rot_phi = np.array([[1, 0, 0, 0], [0, np.cos(ph_r), -np.sin(ph_r), 0], [0, np.sin(ph_r), np.cos(ph_r), 0], [0, 0, 0, 1]])
+        rot_th = np.array([[np.cos(th_r), 0, -np.sin(th_r), 0], [0, 1, 0, 0], [np.sin(th_r), 0, np.cos(th_r), 0], [0, 0, 0, 1]])
+        c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ (rot_th @ rot_phi @ trans)
+        pose = torch.tensor(c2w[:3, :4], dtype=torch.float32)
+        ro, rd = O.get_rays(H, W, focal, pose)
+        ro, rd = ro.reshape(-1, 3).double(), rd.reshape(-1, 3).double()
+        t = torch.linspace(near, far, n_quad, dtype=torch.float64)
+        pts = ro[:, None, :] + rd[:, None, :] * t[None, :, None]
+        d2 = ((pts[:, :, None, :] - c[None, None]) ** 2).sum(-1)
+        dens = amp * torch.exp(-d2 / (2 * sg ** 2))
+        sigma = dens.sum(-1)
+        colr = (dens[..., None] * col).sum(-2) / (sigma[..., None] + 1e-12)
+        alpha = 1 - torch.exp(-sigma * (t[1] - t[0]) * rd.norm(dim=-1, keepdim=True))
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+        images.append(((alpha * T)[..., None] * colr).sum(1).reshape(H, W, 3).float())
+        poses.append(pose)
+    return torch.stack(poses), torch.stack(images)
+
+
+def g19_draws(step_rng, n_pool, n, K):
+    """The draws of ONE step, in this order (the tests re-derive them from G19['step_seed'])."""
+    sel = step_rng.integers(0, n_pool, n)
+    t_rand = torch.tensor(step_rng.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(step_rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(step_rng.standard_normal((K, 3)), dtype=torch.float32)
+    return sel, t_rand, ea, er
+
+
+def psnr_curve_fixture(R, tmp):
+    import math
+    c = G19
+    H, W, focal, near, far, K, n = c["H"], c["W"], c["focal"], c["near"], c["far"], c["K"], c["n_rand"]
+    poses, images = g19_scene(c["scene_seed"], H, W, focal, near, far, c["n_views"])
+    i_test = list(c["i_test"])
+    i_train = [i for i in range(c["n_views"]) if i not in i_test]
+    cfg = O.OracleCfg(netwidth=c["netwidth"], K_samples=K)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, c["seed"], tmp, K_samples=K, no_ndc=True)
+    args.lrate_decay = c["lrate_decay"]
+    for kw in (kw_train, kw_test):                               # RUN:828-832 (bds_dict); create_nerf already set ndc=False (RUN:397-400)
+        kw.update(near=near, far=far)
+    net = model.module
+    erng = np.random.default_rng(c["step_seed"] + 1)            # the eval latents (MOD:50-55 draws them at construction)
+    ea_eval = torch.tensor(erng.standard_normal((K, 1)), dtype=torch.float32)
+    er_eval = torch.tensor(erng.standard_normal((K, 3)), dtype=torch.float32)
+    net.sample_alpha, net.sample_rgb = ea_eval.clone(), er_eval.clone()
+    ro_all, rd_all, tg_all = [], [], []
+    for v in i_train:
+        ro, rd = O.get_rays(H, W, focal, poses[v])
+        ro_all.append(ro.reshape(-1, 3)); rd_all.append(rd.reshape(-1, 3)); tg_all.append(images[v].reshape(-1, 3))
+    ro_all, rd_all, tg_all = torch.cat(ro_all), torch.cat(rd_all), torch.cat(tg_all)
+
+    def held_out():
+        ps = []
+        for v in i_test:
+            with torch.no_grad():
+                rgbs, _, _, _ = R.render(H, W, focal, chunk=8192, c2w=poses[v], **kw_test)
+            ps.append(float(-10. * torch.log(torch.mean((rgbs.mean(-1) - images[v]) ** 2)) / torch.log(torch.tensor(10.))))   # HLP:15-16
+        return ps
+
+    g = dict(poses=poses, images=images, i_test=np.array(i_test), eps_alpha_eval=ea_eval, eps_rgb_eval=er_eval,
+             **{k: (np.array(v) if isinstance(v, tuple) else v) for k, v in c.items() if k != "i_test"})
+    loss_c, nll_c, psnr_c, ent_c, test_steps, test_psnr = [], [], [], [], [0], [held_out()]
+    srng = np.random.default_rng(c["step_seed"])
+    global_step = 0
+    sel_sum = 0
+    for step in range(c["n_steps"]):
+        sel, t_rand, ea, er = g19_draws(srng, ro_all.shape[0], n, K)
+        sel_sum += int(sel.sum())
+        batch_rays = torch.stack([ro_all[sel], rd_all[sel]], 0)
+        target = tg_all[sel]
+        with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+            rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=batch_rays, verbose=False, retraw=False, **kw_train)
+        rgb_mean = rgbs.mean(-1)                                                            # RUN:1027-1029
+        img_loss = torch.mean((rgb_mean - target) ** 2)
+        psnr = -10. * torch.log(img_loss) / torch.log(torch.Tensor([10.]))
+        nk, eps = K, 1e-05                                                                  # RUN:1030-1050
+        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+        H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+        loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+        loss_entropy = extras["loss_entropy"].mean()
+        loss = loss_nll + c["beta1"] * loss_entropy
+        optimizer.zero_grad()                                                               # RUN:1065-1067
+        loss.backward()
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))         # RUN:1073-1077
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = new_lrate
+        global_step += 1
+        loss_c.append(float(loss)); nll_c.append(float(loss_nll)); psnr_c.append(float(psnr)); ent_c.append(float(loss_entropy))
+        if (step + 1) % c["every"] == 0:
+            test_steps.append(step + 1); test_psnr.append(held_out())
+    g.update(loss=np.array(loss_c), loss_nll=np.array(nll_c), psnr_train=np.array(psnr_c), entropy=np.array(ent_c),
+             test_steps=np.array(test_steps), psnr_test=np.array(test_psnr), sel_checksum=np.array(sel_sum))
+    return g
+
+
 def t2n(d):
     out = {}
     for k, v in d.items():
@@ -568,6 +682,13 @@ def main():
         if v.grad is not None:
             g18["grad." + k[len("module."):]] = v.grad.clone()
     out["g18_train_k100"] = g18
+
+    # ---------------- G19: PSNR-vs-step of the REFERENCE ITSELF, trained here for 120 steps with its own loop lines (RUN:1013-1077) on a
+    #                  tiny procedural scene ("train both reference (CPU, few hundred steps, only here) and build, compare
+    #                  PSNR-vs-step curves").  The fixture holds the scene (poses, images), the seeds of every draw, and the reference's
+    #                  per-step loss / train-batch PSNR (RUN:1027-1029) and held-out PSNR of the K-mean prediction at four checkpoints.
+    g19 = psnr_curve_fixture(R, tmp)
+    out["g19_psnr_curve"] = g19
 
     import hashlib
     import json

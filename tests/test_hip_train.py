@@ -275,6 +275,25 @@ def test_three_steps_vs_reference_golden(golden):
     assert float(d.median()) <= 5e-6 and float((d > 1e-4).double().mean()) <= 0.03, (float(d.median()), float((d > 1e-4).double().mean()))
 
 
+@pytest.mark.parametrize("precision", [None, "bf16x3"])
+def test_psnr_curve_of_the_references_own_training_run(golden, precision):
+    """G19 ("train both reference and build, compare PSNR-vs-step curves"): the REFERENCE was trained in the build
+    container for 120 steps with its own loop lines (RUN:1013-1077) on a tiny procedural scene; the HIP path - same weights,
+    batches, jitter, latents, its own ray kernel / Trainer / Adam - reproduces the reference's per-step loss and train-batch PSNR
+    (RUN:1027-1029) and its held-out K-mean PSNR at steps 0 / 40 / 80 / 120 (bounds and measurements: tests/g19_common.py)."""
+    import g19_common as GC
+    g = golden("g19_psnr_curve")
+    dl, dp, held = GC.hip_curve(g, precision)
+    for a, b, tol_loss, tol_psnr in GC.CURVE_BOUNDS:
+        assert dl[a:b].max() <= tol_loss, (a, b, float(dl[a:b].max()))
+        assert dp[a:b].max() <= tol_psnr, (a, b, float(dp[a:b].max()))
+    assert sorted(held) == sorted(GC.HELD_OUT_BOUNDS)
+    for step, tol in GC.HELD_OUT_BOUNDS.items():
+        assert np.abs(held[step]).max() <= tol, (step, held[step])
+    # ... and training did something: the reference's held-out PSNR rose by > 4 dB over the run
+    assert float(np.mean(g["psnr_test"][-1]) - np.mean(g["psnr_test"][0])) > 4.0
+
+
 def test_adam_kernel_on_the_references_own_gradients(golden):
     """G15: cfnerf_adam_step driven with the gradients the REFERENCE fed torch.optim.Adam at each of three steps (and
     the learning rates its loop wrote back, RUN:1073-1077): bias corrections at t = 1, 2, 3, the moment updates and the

@@ -388,6 +388,49 @@ def test_fixtures_match_the_manifest(golden):
             assert _digest(v) == man[name][k], (name, k)
 
 
+def test_psnr_curve_of_the_reference_first_40_steps(golden):
+    """G19: the REFERENCE's own training run (its loop lines RUN:1013-1077, 120 steps on a tiny procedural scene).  The oracle,
+    driven with the same batches / jitter / latents (re-derived from the fixture's seed), follows its loss and train-batch PSNR
+    (RUN:1027-1029) for the first 40 steps and its held-out K-mean PSNR at steps 0 and 40.  (All 120 steps: the -m gpu test.)"""
+    import g19_common as GC
+    g = golden("g19_psnr_curve")
+    H, W, focal, near, far = int(g["H"]), int(g["W"]), float(g["focal"]), float(g["near"]), float(g["far"])
+    K, n = int(g["K"]), int(g["n_rand"])
+    cfg = cfg_from(g)
+    p = O.make_params(cfg, int(g["seed"]))
+    poses, images = T(g["poses"]), T(g["images"])
+    i_train, i_test = GC.views(g)
+    ro_all, rd_all, tg_all = [], [], []
+    for v in i_train:
+        ro, rd = O.get_rays(H, W, focal, poses[v])
+        ro_all.append(ro.reshape(-1, 3)); rd_all.append(rd.reshape(-1, 3)); tg_all.append(images[v].reshape(-1, 3))
+    ro_all, rd_all, tg_all = torch.cat(ro_all), torch.cat(rd_all), torch.cat(tg_all)
+    ea_e, er_e = T(g["eps_alpha_eval"]).clone(), T(g["eps_rgb_eval"]).clone()
+    ea_e[-1] = 0                                                            # MOD:199,205
+    er_e[-1] = 0
+
+    def held_out():
+        out = []
+        for v in i_test:
+            with torch.no_grad():
+                o = O.render(p, H, W, focal, cfg, ea_e, er_e, False, c2w=poses[v], ndc=False, near=near, far=far)
+            out.append(GC.psnr_of(o["rgb_map"].mean(-1), images[v]))
+        return out
+
+    close(held_out(), g["psnr_test"][0], atol=1e-4, rtol=0, what="held-out PSNR at step 0")
+    rng = np.random.default_rng(int(g["step_seed"]))
+    state, sel_sum = {}, 0
+    for s in range(40):
+        sel, t_rand, ea, er = GC.draws(rng, ro_all.shape[0], n, K)
+        sel_sum += int(sel.sum())
+        packed = O.pack_rays(H, W, focal, ro_all[sel], rd_all[sel], False, near, far)
+        scal, grads, _ = O.train_step(p, packed, tg_all[sel], cfg, ea, er, t_rand, float(g["beta1"]))
+        p = O.adam_step(p, grads, state, s + 1, GC.lr_of_step(float(g["lrate"]), int(g["lrate_decay"]), s))
+        close(scal["loss"], g["loss"][s], atol=2e-5, rtol=1e-5, what=f"loss at step {s}")
+        close(scal["psnr"], g["psnr_train"][s], atol=1e-3, rtol=0, what=f"train-batch PSNR at step {s}")
+    close(held_out(), g["psnr_test"][1], atol=1e-3, rtol=0, what="held-out PSNR at step 40")
+
+
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/model"), reason="the reference only exists in the build container")
 def test_committed_generator_reproduces_the_fixtures(tmp_path):
     """Build container only: re-run the committed generator against the real reference and compare every array of every
