@@ -321,6 +321,31 @@ def psnr_block(dev, steps, n_rand=1024, K=4):
     return out
 
 
+def psnr_reference_run_agreement():
+    """Pass/fail against the REFERENCE ITSELF: fixture tests/golden/g19_psnr_curve.npz is the real reference trained in the build
+    container for 120 steps with its own loop lines (RUN:1013-1077) on a tiny procedural scene (data only: scene, seeds, its loss /
+    PSNR curves).  The HIP path re-runs those 120 steps with the same weights, batches, jitter and latents; its per-step loss,
+    train-batch PSNR and held-out K-mean PSNR (steps 0 / 40 / 80 / 120) must stay inside the bounds of the -m gpu test
+    (tests/g19_common.py).  Part of the cpu_baseline leg (the weights come from the oracle's deterministic generator)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import numpy as np
+    import g19_common as GC
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g19_psnr_curve.npz")))
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(sys.stderr):
+        dl, dp, held = GC.hip_curve(g)
+    ok = all(dl[a:b].max() <= tl and dp[a:b].max() <= tp for a, b, tl, tp in GC.CURVE_BOUNDS) and \
+        all(float(np.abs(held[k]).max()) <= tol for k, tol in GC.HELD_OUT_BOUNDS.items())
+    last = int(g["n_steps"])
+    return {"what": "HIP path vs the real reference's own 120-step training run (fixture G19: its loop lines RUN:1013-1077, N_rand 128, K 4, "
+                    "W 64, procedural 24x32 scene), same weights / batches / jitter / latents",
+            "reference_held_out_psnr_db": {str(int(s)): round(float(np.mean(v)), 3) for s, v in zip(g["test_steps"], g["psnr_test"])},
+            "max_abs_held_out_psnr_diff_db": {str(k): float(np.abs(v).max()) for k, v in held.items()},
+            "max_abs_train_psnr_diff_db": float(dp.max()), "max_rel_loss_diff": float(dl.max()),
+            "tolerance_db_at_last_step": GC.HELD_OUT_BOUNDS[last], "agree": bool(ok), "seconds": round(time.perf_counter() - t0, 2)}
+
+
 def psnr_oracle_agreement(dev, steps=25, n_rand=256, K=4, tol_db=0.05):
     """Pass/fail: the HIP path and the CPU oracle train on the procedural scene from IDENTICAL weights with identical rays,
     targets, jitter and latents every step; their held-out PSNR must agree at step 0 and after `steps` steps (studied over 300
@@ -587,6 +612,7 @@ def main():
                 wl.__dict__.pop("trainer", None)
                 wl.net.release_workspace()
                 psnr["vs_oracle"] = psnr_oracle_agreement(dev)
+                psnr["vs_reference_run"] = psnr_reference_run_agreement()
 
     # the JSON line is the LAST thing on stdout: RCCL prints its version banner through libc's buffered stdout (it would
     # otherwise surface at process exit, after the line), so every rank flushes that before the final barrier

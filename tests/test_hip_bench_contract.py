@@ -78,6 +78,10 @@ def test_psnr_block_is_in_the_default_line():
     assert p["value"] == c["300"]
     v = p["vs_oracle"]
     assert v["agree"] is True and v["abs_psnr_diff_db_step0"] <= 1e-3 and v["abs_psnr_diff_db_step25"] <= v["tolerance_db"]
+    r = p["vs_reference_run"]               # ... and against the real reference's own 120-step training run (fixture G19)
+    assert r["agree"] is True and set(r["max_abs_held_out_psnr_diff_db"]) == {"0", "40", "80", "120"}
+    assert r["max_abs_held_out_psnr_diff_db"]["120"] <= r["tolerance_db_at_last_step"] <= 0.01
+    assert r["reference_held_out_psnr_db"]["120"] > r["reference_held_out_psnr_db"]["0"] + 4.0
     for k in ("alt_precision", "stress_w512", "alt_config", "cpu_baseline"):
         assert k in d, k
 

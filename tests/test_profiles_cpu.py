@@ -33,6 +33,8 @@ def test_bench_lines_carry_the_contract(name, workload):
         # the second half of the headline metric, in the line itself (synthetic stand-in scene) + the HIP-vs-oracle agreement
         p = d["psnr"]
         assert "synthetic stand-in for LLFF-fern" in p["scene"] and p["unit"] == "dB" and p["value"] > 30.0 and p["vs_oracle"]["agree"] is True
+        # ... and the agreement with the REAL reference's own 120-step training run (fixture G19)
+        assert p["vs_reference_run"]["agree"] is True and p["vs_reference_run"]["max_abs_held_out_psnr_diff_db"]["120"] <= 0.01
 
 
 @pytest.mark.parametrize("bench,stats,kernel", [("c2", "train", "fused_fwd_kernel<256, 0, true, 0>"), ("eval", "eval", "fused_fwd_kernel<256, 0, false, 0>"),
