@@ -20,10 +20,8 @@ torch in the reference's order (RUN:524 -> MOD:234 -> MOD:246).
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from collections import OrderedDict
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -8,7 +8,6 @@ re-shuffled exactly like RUN:946-949.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 

@@ -10,7 +10,6 @@ uncertainty maps of RUN:1117-1131, sparsification_plot HLP:382-438).
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 import torch

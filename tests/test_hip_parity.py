@@ -6,7 +6,7 @@ import torch
 
 import cfnerf_amd
 from oracle import cfnerf_oracle as O
-from util_hip import ATOL, ATOL_DISP, RTOL, build_model, close, fern_rays, make_args
+from util_hip import ATOL_DISP, build_model, close, fern_rays, make_args
 
 pytestmark = pytest.mark.gpu
 T = lambda a: torch.tensor(np.asarray(a))
