@@ -167,6 +167,8 @@ class Workload:
         # step, so the per-stage breakdown is taken in a few extra steps AFTER the timed region (stage_ms)
         self.lib.cfnerf_timing_enable(self.net.handle, 2)
         self.net.set_precision(precision)
+        if os.environ.get("CFNERF_BENCH_FLOW_MATH"):            # development A/B only: auto (default) | libm | fast
+            self.net.set_flow_math(os.environ["CFNERF_BENCH_FLOW_MATH"])
         self.cfnerf = cfnerf_amd
         self.g = torch.Generator(device=dev).manual_seed(1234)  # explicit latents: same on every rank (Trainer enforces it otherwise)
         H, Wd, focal = sc["H"], sc["W"], sc["focal"]
