@@ -284,6 +284,64 @@ def launch_ranks(n, argv):
     return 0
 
 
+def live_pmc(mode, budget_s=150.0):
+    """HBM traffic and matrix-pipe occupancy of the fused forward kernel OBSERVED BY THIS RUN: before this process touches the GPU it
+    runs the same workload (3 steps) as a CHILD under `rocprofv3 --kernel-trace --pmc ...`, one pass per counter group (FETCH_SIZE;
+    WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE - counters in their own passes, no other trace domain, the program itself
+    after `--`), and reads the per-dispatch means of the kernel from the counter CSV.  Corrections as MI355X_MICROARCH.md prescribes
+    (FETCH_SIZE / WRITE_SIZE are KB; gfx950 reports half of a wide coalesced read: FETCH doubled).  Returns None - and the line falls
+    back to the committed profiles/ figures, saying so - when rocprofv3 is absent, a pass fails or the time budget runs out."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    t_end = time.monotonic() + budget_s
+    env = dict(os.environ, CFNERF_BENCH_LIVE_PMC="0", TMPDIR="/tmp")
+    got = {}
+    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")):
+        left = t_end - time.monotonic()
+        if left < 25:
+            return None
+        with tempfile.TemporaryDirectory(prefix="cfnerf_pmc_", dir="/tmp") as d:
+            cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline", "--mode", mode]
+            try:
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            except OSError:
+                return None
+            try:
+                proc.wait(timeout=min(left, 90.0))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
+                except OSError:
+                    pass
+                proc.wait()
+                return None
+            if proc.returncode != 0:
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            acc = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if "fused_fwd_kernel" in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c in group:
+                if not acc.get(c):
+                    return None
+                got[c] = sum(acc[c]) / len(acc[c])
+    return {"hbm_bytes_per_launch": (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0,
+            "FETCH_SIZE_KB": got["FETCH_SIZE"], "WRITE_SIZE_KB": got["WRITE_SIZE"],
+            "mfma_busy_frac": got["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * got["GRBM_GUI_ACTIVE"] / 8.0)}
+
+
 def psnr_block(dev, steps, n_rand=1024, K=4):
     """PSNR half of the headline metric (RUN:1027-1029: mse2psnr(img2mse(mean_K rgb, target))).  No LLFF-fern data exists
     here, so the scene is the procedural stand-in of tools/procedural_scene.py, trained through the device ray pool +
@@ -428,6 +486,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher above us: start the ranks ourselves (nothing in this process has touched the GPU yet)
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # counters of the dominant kernel observed by this very run (default one-GPU line only; child passes BEFORE the first GPU call here)
+    live = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_alt and args.config is None and args.precision == "fp32"
+            and os.environ.get("CFNERF_BENCH_LIVE_PMC", "1") != "0"):
+        live = live_pmc(args.mode or "train")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -574,11 +638,19 @@ def main():
                 break
             except Exception:
                 continue
+        traffic_unit = (f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 --pmc passes, profiles/{src}; not "
+                        f"re-measured by this run)") if src else None
+        if live is not None:
+            traffic, mfma_busy = live["hbm_bytes_per_launch"], live["mfma_busy_frac"]
+            traffic_unit = ("bytes/launch, OBSERVED BY THIS RUN: rocprofv3 --kernel-trace --pmc child passes of the same workload (3 steps each: "
+                            "FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE) before the timed region; FETCH_SIZE x2 per "
+                            "MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read), KB -> bytes")
         roof = {"bound": "mfma", "kernel": f"fused_fwd_kernel<{wl.W},rays,{'train' if mode == 'train' else 'eval'}>",
                 "achieved": fl / (fwd_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "traffic": traffic,
-                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 --pmc passes, profiles/{src}; not "
-                                f"re-measured by this run)" if src else None,
+                "traffic_unit": traffic_unit, "traffic_source": "live" if live is not None else ("profiles/" + src if src else None),
                 "mfma_busy_frac_pmc": mfma_busy, "launch_ms": fwd_ms, "flops_per_launch": fl}
+        if live is not None:
+            roof["pmc_live"] = {"FETCH_SIZE_KB": live["FETCH_SIZE_KB"], "WRITE_SIZE_KB": live["WRITE_SIZE_KB"]}
         roof["frac"] = roof["achieved"] / roof["peak"]
         sm = sorted(step_ms)
         out = {

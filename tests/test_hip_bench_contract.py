@@ -22,7 +22,9 @@ def run_bench(*args, env=None, timeout=900):
     with tempfile.NamedTemporaryFile("r", suffix=".out", delete=False) as f:
         path = f.name
     try:
-        p = ctx.Process(target=mp_workers.bench_child, args=(list(args), path, dict(env or {})))
+        env = dict(env or {})
+        env.setdefault("CFNERF_BENCH_LIVE_PMC", "0")        # the rocprofv3 child passes of the default line: only where a test asks for them
+        p = ctx.Process(target=mp_workers.bench_child, args=(list(args), path, env))
         p.start()
         p.join(timeout)
         assert p.exitcode == 0, f"bench.py {' '.join(args)} exited with {p.exitcode}"
@@ -66,6 +68,20 @@ def test_eval_mode_and_other_configs_run():
     assert "stress_w512" not in d and "alt_config" not in d and "psnr" not in d and "kernel_ms" not in d
     d = run_bench("--config", "C4", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline")
     assert d["config"]["workload"].startswith("C4") and "K=16" in d["config"]["workload"]
+
+
+def test_default_line_observes_its_own_counters():
+    """roofline.traffic / mfma_busy_frac_pmc of the default line are measured by the run itself: rocprofv3 --pmc child passes of the same
+    workload, started before the bench process touches the GPU (falls back to the committed figures only without rocprofv3)."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    d = run_bench("--steps", "4", "--warmup", "1", "--psnr-steps", "0", "--no-cpu-baseline", env={"CFNERF_BENCH_LIVE_PMC": "1"})
+    r = d["roofline"]
+    assert r["traffic_source"] == "live" and "OBSERVED BY THIS RUN" in r["traffic_unit"]
+    # train forward: ~1.46 GB of stash written + ~0.1 GB read per launch; matrix pipe 75-90 % busy
+    assert 1.2e9 <= r["traffic"] <= 2.2e9 and 0.6 <= r["mfma_busy_frac_pmc"] <= 0.95
+    assert abs(r["traffic"] - (2 * r["pmc_live"]["FETCH_SIZE_KB"] + r["pmc_live"]["WRITE_SIZE_KB"]) * 1024) <= 1e-6 * r["traffic"]
 
 
 def test_psnr_block_is_in_the_default_line():
