@@ -300,6 +300,9 @@ def live_pmc(mode, budget_s=150.0):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
+    # under a profiler this process may already hold the GPU (its preloaded tool library initialises it): starting children is off limits
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.upper().startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     t_end = time.monotonic() + budget_s
     env = dict(os.environ, CFNERF_BENCH_LIVE_PMC="0", TMPDIR="/tmp")
     got = {}
