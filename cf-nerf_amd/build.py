@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcfnerf_hip.so")
+CONSUMER = os.path.join(OBJ, "abi_consumer")
 SOURCES = ["cfnerf_fwd.hip", "cfnerf_bwd.hip", "cfnerf_abi.hip"]
 # -ffp-contract=off: the sampling / encoding arithmetic must round like the reference's separate
 # torch ops (an fma in pts = o + d*z moves sin(2^9 x) by ~3e-5); MFMA code is unaffected.
@@ -51,6 +52,15 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    # the plain-C consumer of the ABI (tests/abi_consumer.c: gcc -std=c99 over include/cfnerf.h + the HIP runtime's C API)
+    root = os.path.dirname(HERE)
+    csrc = os.path.join(root, "tests", "abi_consumer.c")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc and os.path.exists(csrc) and (force or _newer(CONSUMER, [csrc, os.path.join(root, "include", "cfnerf.h"), LIB])):
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        run([cc, "-std=c99", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I" + os.path.join(rocm, "include"), csrc,
+             "-o", CONSUMER, "-L" + HERE, "-lcfnerf_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lm",
+             "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
     return LIB
 
 

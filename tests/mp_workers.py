@@ -79,3 +79,12 @@ def bench_child(argv, out_path, env):
             print(e.code, file=sys.stderr)
         os._exit(code)
     sys.stdout.flush()
+
+
+def run_program(cmd, out_path):
+    """Run an external program from a FRESH fork-server child (a process that has never touched the GPU may fork + exec); its
+    stdout + stderr go to `out_path`, its exit code becomes this child's."""
+    import subprocess
+    with open(out_path, "w") as f:
+        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT)
+    os._exit(r.returncode if 0 <= r.returncode < 256 else 255)

@@ -282,3 +282,31 @@ def test_bench_gpus_n_without_enough_gpus_fails_cleanly():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "--gpus 64" in r.stderr and "CFNERF_BENCH_SAME_GPU" in r.stderr and r.stdout.strip() == ""
+
+
+def test_header_is_plain_c_and_the_c_consumer_builds():
+    """include/cfnerf.h compiles as C99 (no C++, no torch types), and tests/abi_consumer.c - a plain C program over it - was built
+    by cf-nerf_amd/build.py; without a device it gets through the host-side checks (layout query, NULL-model refusal) and then
+    fails loudly at hipSetDevice.  (With a device: tests/test_hip_abi_consumer.py.)"""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc")
+    if cc is None:
+        pytest.skip("no gcc")
+    r = subprocess.run([cc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "cfnerf.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = os.path.join(root, "cf-nerf_amd", "build", "abi_consumer")
+    assert os.path.exists(exe)
+    if os.path.exists("/dev/kfd"):
+        return                                   # (a GPU box: the -m gpu test runs it for real)
+    import numpy as np
+    import test_hip_abi_consumer as TC
+    g = dict(np.load(os.path.join(root, "tests", "golden", "g57_render_w64_ndc.npz")))
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case.bin")
+        TC.write_case(case, g)
+        r = subprocess.run([exe, case], capture_output=True, text=True)
+    assert r.returncode == 2 and "device" in r.stderr.lower(), (r.returncode, r.stderr)
