@@ -53,11 +53,7 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
 }
 
 // 16*NV MFMAs of one k-chunk (8 k values): a0/a1 = A fragments of the two row tiles, b[j] = B fragments
-#ifdef CFN_ASYM_PRIO
-#define CFN_SETPRIO(x) ((void)0)
-#else
 #define CFN_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 #ifndef CFN_MMA_PRIO
 #define CFN_MMA_PRIO 0
 #endif

@@ -123,9 +123,6 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
     const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
     const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
 
-#ifdef CFN_ASYM_PRIO
-    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef CFN_TIMESTAMP
     const unsigned long long t_start = wall_clock64();
     int dbg_n = 0;
