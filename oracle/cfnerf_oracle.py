@@ -281,6 +281,12 @@ def sylvester_flow(p: Dict[str, Tensor], name: str, z0: Tensor, h: Tensor, n_flo
 # --------------------------------------------------------------------------
 # NeRF_Flows.forward  (MOD:188-291)
 # --------------------------------------------------------------------------
+# TEST HOOK (not part of the restated algorithm): a dict that receives alpha0 [P K,1] / rgb0 [P K,3] of the next forward WITH their
+# autograd history, so a gradient test can ask for d loss / d alpha0 per (point, latent): the gradient of alpha_mean is the plain
+# sum of those terms, and its fp32 rounding error scales with the sum of their magnitudes, not with the (cancelling) sum itself.
+latent_tap = None
+
+
 def nerf_flows_forward(p: Dict[str, Tensor], x: Tensor, eps_alpha: Tensor, eps_rgb: Tensor,
                        cfg: OracleCfg, is_test: bool):
     """x [P,90]; eps_alpha [K,1]; eps_rgb [K,3] -> (raw [P,K,4], entropy scalar | None).
@@ -297,6 +303,8 @@ def nerf_flows_forward(p: Dict[str, Tensor], x: Tensor, eps_alpha: Tensor, eps_r
     rgb_mean_k = p["rgb_mean"][None, None, :].expand(BN, K, 3)
     rgb_std_k = p["rgb_std"][None, None, :].expand(BN, K, 3)
     rgb0 = (eps_rgb[None].expand(BN, K, 3) * rgb_std_k + rgb_mean_k).reshape(-1, 3)           # MOD:206/251
+    if latent_tap is not None:          # TEST HOOK: the base samples as graph nodes (per-element gradient contributions of the base Gaussians)
+        latent_tap["alpha0"], latent_tap["rgb0"] = alpha0, rgb0
 
     ha = h_alpha[:, None, :].expand(BN, K, cfg.h_alpha_size).reshape(-1, cfg.h_alpha_size)    # MOD:210-211
     hr = h_rgb[:, None, :].expand(BN, K, cfg.h_rgb_size).reshape(-1, cfg.h_rgb_size)          # MOD:215-216
