@@ -667,6 +667,9 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr, n_flows=nf)
     _, kw_train, _, model, p, _ = build_model(cfg, 700 + seed, no_ndc=not ndc, lindisp=lindisp, white_bkgd=wb)
     net = model.module
+    import os
+    if os.environ.get("CFNERF_FUZZ_PREC"):               # soak of the opt-in mode: CFNERF_FUZZ_PREC=bf16x3
+        net.set_precision(os.environ["CFNERF_FUZZ_PREC"])
     rays, (H, Wd, focal) = fern_rays(rng, N)
     near, far = (0., 1.) if ndc else (1.2, 8.0)
     t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32) if perturb else None
