@@ -672,7 +672,10 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
         net.set_precision(os.environ["CFNERF_FUZZ_PREC"])
     rays, (H, Wd, focal) = fern_rays(rng, N)
     near, far = (0., 1.) if ndc else (1.2, 8.0)
-    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32) if perturb else None
+    # (soak seeds >= 2000: sample tables other than the reference's 128 entries - ragged last tile, one tile, many tiles)
+    S = 128 if seed < 2000 else int(rng.choice([16, 64, 100, 128, 130, 192, 257]))
+    t_vals = None if S == 128 else torch.linspace(0., 1., S)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32) if perturb else None
     ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
     er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
     target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
@@ -680,10 +683,11 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     tr = TR.Trainer(net, beta1=beta1)
     grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=None if t_rand is None else t_rand.to(DEV),
                                eps=torch.cat([er, ea], -1).to(DEV), near=near, far=far, ndc=ndc, lindisp=lindisp, white_bkgd=wb,
-                               perturb=1. if perturb else 0.).cpu()
+                               perturb=1. if perturb else 0., t_vals=None if t_vals is None else t_vals.to(DEV)).cpu()
     packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
-    scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb)
-    what = f"[W={W} D={D} K={K} ha={ha} hr={hr} F={nf} N={N} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
+    scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb,
+                                                         t_vals=t_vals)
+    what = f"[W={W} D={D} K={K} ha={ha} hr={hr} F={nf} N={N} S={S} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
     close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map " + what)
     close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)

@@ -220,7 +220,7 @@ def grad_close_tight(g, ref, what, tol=None):
     nx = G_NOISE_X * (G_ALPHA_X if ("alpha" in what) else 1.0)
     if tol is None:
         tol = G_TIGHT if noise is None else min(max(nx * noise, G_FLOOR), G_CAP)
-    tol_rms = tol if noise is None else min(max(0.75 * nx * noise, 1.5 * G_FLOOR), G_CAP)
+    tol_rms = tol if noise is None else min(max(nx * noise, 1.5 * G_FLOOR), G_CAP)
     scale = max(float(np.abs(ref).max()), 1e-12)
     rms_rel = float(np.sqrt(((g - ref) ** 2).sum() / max(float((ref ** 2).sum()), 1e-300)))
     stats = os.environ.get("CFNERF_GRAD_STATS")          # development aid: log the measured error of every comparison
