@@ -659,6 +659,8 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     ha = int(rng.choice([32, 64, 96, 128] if W <= 256 else [32, 64, 96]))
     hr = int(rng.choice([h for h in (32, 64, 96, 128) if W // 2 + h <= max(W, 128)]))
     N = int(rng.integers(3, 24))
+    if seed >= 3000:                                     # (soak: MANY rays through a small network - every workgroup walks several rays)
+        W, D, K, ha, hr, N = 64, int(rng.choice([4, 5])), int(rng.choice([2, 3, 4])), 32, 32, int(rng.integers(600, 1500))
     ndc = bool(rng.integers(0, 2))
     lindisp = (not ndc) and bool(rng.integers(0, 2))
     wb = bool(rng.integers(0, 2))
