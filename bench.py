@@ -560,9 +560,11 @@ def main():
         # its own roofline: three bf16 MFMAs per fp32 product on the 2.5 PFLOP/s dense bf16 matrix pipe
         alt["roofline"] = {"bound": "mfma (bf16 pipe, 3 MFMAs per fp32 product)", "peak": 2500.0 / 3, "unit": "fp32-equivalent TFLOP/s",
                            "achieved": alt["fwd_fp32_equiv_tflops"], "frac": alt["fwd_fp32_equiv_tflops"] / (2500.0 / 3),
-                           "note": "PMC: the matrix pipe is 33-42 % busy in this mode; the bf16 MFMA does not co-issue with other vector "
-                                   "instructions either and the mode carries 2.6x as many of them (hi/lo splits, v_perm de-interleaves) "
-                                   "as the fp32 path (profiles/r03_pmc_summary.txt section pmc_b16, DESIGN.md section 3)"}
+                           "note": "PMC (train forward, per tile and wave): 1 809 MFMAs = 38 % of the time, 7 970 other vector instructions "
+                                   "(hi/lo split of every epilogue element, mask bits, flows) = 23 % - the bf16 MFMA does not co-issue with them "
+                                   "either - and 38 % stalls at the 2.07 GHz this kernel clocks; costed in round 3: a free activation stash "
+                                   "would give 0.40, the remaining candidates sum to 0.42-0.45 (profiles/r03_pmc_summary.txt section pmc_b16, "
+                                   "DESIGN.md section 3 'Measured and rejected', round 3)"}
 
     # BASELINE config 4 (K = 16, 1024 rays per GPU) next to the line when the job spans several GPUs (default run only)
     cfg4 = None
