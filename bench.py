@@ -14,10 +14,15 @@ A "step" is one pass of the hot path over one batch of synthetic rays of a BASEL
   C5  800 x 800 full-image eval, K 32, white background, rows tiled across ranks, fused uncertainty maps - eval
   C1  N_rand 256, K 1 - forward only (the reference's K = 1 train loss is NaN)
   W512  the authors' recipe (train_NF.sh): W 512, h_alpha 64, K 32, N_rand 512 - train step ("stress row" of SURVEY 8d)
+  K64   the reference's DEFAULT latent count (--K_samples 64, RUN:631): N_rand 1024, W 256 - train step
 S = 128 samples always (the reference's hard-coded table; single pass - it has no fine network).
   --mode train: forward + KDE-NLL loss + backward + Adam;  --mode eval: fused forward render only.
 Rays are sharded across ranks (weak scaling: rays per GPU fixed); the only exchange is one RCCL all-reduce of the flat
-gradient per train step.  Prints ONE JSON line on rank 0.
+gradient per train step.  Prints ONE JSON line on rank 0.  At N > 1 the line explains itself: `comm` (exposed exchange time
+per step from two HIP events around the all-reduce on the compute stream, payload, the backend and world size torch.distributed
+reports), `rank_skew` (min / max over ranks of the step and forward-kernel times), `psnr` (the sharded ray pool + Trainer on the
+stand-in scene, with `vs_single_process`), `cpu_baseline` (rank 0).  Exit codes: 2 = fewer GPUs than --gpus, 3 = the process
+group could not be initialised or does not span --gpus ranks.
 """
 import argparse
 import json
@@ -43,6 +48,7 @@ CONFIGS = {
     "C5": dict(n=None, K=32, W=256, ha=32, mode="eval", scene="blender", what="800x800 full-image eval (Blender intrinsics, near 2 / far 6, white background, "
                                                                                "no NDC), rows tiled across ranks, fused K-statistics (uncertainty maps)"),
     "W512": dict(n=512, K=32, W=512, ha=64, mode="train", scene="fern", what="the authors' recipe (train_NF.sh): W=512, h_alpha=64, K=32, N_rand=512"),
+    "K64": dict(n=1024, K=64, W=256, ha=32, mode="train", scene="fern", what="LLFF-fern-shaped NDC rays at the reference's default K_samples=64 (RUN:631)"),
 }
 
 
@@ -186,7 +192,7 @@ class Workload:
         if self.mode == "train":
             from cfnerf_amd import train as T
             self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist,
-                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "0") == "1")
+                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "0") == "1", time_comm=world > 1 or force_dist)
         self.hier = hierarchical
 
     def step(self):
@@ -258,8 +264,13 @@ def launch_ranks(n, argv):
     import socket
     import subprocess
     same_gpu = os.environ.get("CFNERF_BENCH_SAME_GPU") == "1"
-    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if not same_gpu and have < n:
+    # count devices WITHOUT initialising HIP in this process (it is about to fork + exec the launcher): the amdsmi path only; a negative
+    # answer means "unknown" (torch.cuda.device_count() would then fall back to hipGetDeviceCount) - the ranks report a missing device
+    try:
+        have = int(torch.cuda._device_count_amdsmi())
+    except Exception:
+        have = -1
+    if not same_gpu and 0 <= have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (CFNERF_BENCH_SAME_GPU=1 runs the N-rank code path on one GPU over gloo)",
               file=sys.stderr)
         return 2
@@ -345,42 +356,107 @@ def live_pmc(mode, budget_s=150.0):
             "mfma_busy_frac": got["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * got["GRBM_GUI_ACTIVE"] / 8.0)}
 
 
-def psnr_block(dev, steps, n_rand=1024, K=4):
+PSNR_NOTE = ("the end value of this chaotic trajectory re-rolls by a few dB with any change of arithmetic (35.1 / 36.3 / 38.2 dB at 2000 steps over "
+             "round 3's builds, same seeds): it shows that the path trains; the PINS are vs_reference_run (the real reference's own run, fixture "
+             "G19), vs_oracle and - at N > 1 - vs_single_process")
+
+
+def _psnr_net(dev, K):
+    import contextlib
+    import cfnerf_amd
+    torch.manual_seed(0)                        # the reference constructor's RNG stream is replayed on the CPU: same weights on every rank
+    with contextlib.redirect_stdout(sys.stderr):
+        kw_train, _, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=256, K_samples=K, device=dev, no_ndc=True,
+                                                                             dataset_type="blender"))
+    return kw_train["network_fn"].module
+
+
+def psnr_block(dev, steps, n_rand=1024, K=4, rank=0, world=1):
     """PSNR half of the headline metric (RUN:1027-1029: mse2psnr(img2mse(mean_K rgb, target))).  No LLFF-fern data exists
     here, so the scene is the procedural stand-in of tools/procedural_scene.py, trained through the device ray pool +
-    the fused Trainer; held-out PSNR of the K-mean prediction at a few checkpoints."""
-    import contextlib
+    the fused Trainer; held-out PSNR of the K-mean prediction at a few checkpoints.  N > 1: the pool is SHARDED (one permutation for
+    all ranks, rank r takes its N_rand rows of the step's world x N_rand window), the global batch is world x n_rand rays, the Trainer
+    all-reduces the gradient and enforces one set of latents per step; rank 0 evaluates."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import procedural_scene as PS
     import cfnerf_amd
     from cfnerf_amd import train as T
     poses, images, i_train, i_test = PS.make(dev)
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(sys.stderr):
-        kw_train, _, _, _, _ = cfnerf_amd.create_nerf(cfnerf_amd.default_args(netwidth=256, K_samples=K, device=dev, no_ndc=True,
-                                                                             dataset_type="blender"))
-    net = kw_train["network_fn"].module
-    pool = cfnerf_amd.RayPool(images, poses, PS.H, PS.W, PS.FOCAL, i_train, n_rand, generator=torch.Generator(device=dev).manual_seed(1))
-    tr = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01)
-    g = torch.Generator(device=dev).manual_seed(2)
+    net = _psnr_net(dev, K)
+    if world == 1:
+        pool = cfnerf_amd.RayPool(images, poses, PS.H, PS.W, PS.FOCAL, i_train, n_rand, generator=torch.Generator(device=dev).manual_seed(1))
+    else:
+        pool = cfnerf_amd.RayPool(images, poses, PS.H, PS.W, PS.FOCAL, i_train, n_rand, rank=rank, world=world,
+                                  generator=torch.Generator(device=dev).manual_seed(1))      # sync="auto": rank 0's permutation, broadcast per epoch
+    tr = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world)
+    g = torch.Generator(device=dev).manual_seed(2 + rank)                                    # jitter: independent per ray
     marks = sorted({0, min(250, steps), min(1000, steps), steps})
-    curve = {0: PS.held_out_psnr(net, poses, images, i_test, dev)}
+    curve = {0: PS.held_out_psnr(net, poses, images, i_test, dev)} if rank == 0 else {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(1, steps + 1):
         rays, target = pool.next_batch()
-        sc = tr.step(PS.H, PS.W, PS.FOCAL, rays, target.contiguous(), t_rand=torch.rand(n_rand, S, device=dev, generator=g),
-                     eps=torch.randn(K, 4, device=dev, generator=g), near=PS.NEAR, far=PS.FAR, ndc=False)
-        if it in marks:
+        n = rays.shape[1]
+        # one rank: explicit latents from the seeded generator (as rounds 1-3); several: the Trainer's own mechanism (rank 0 draws,
+        # the latents of step t + 1 ride in the tail of step t's gradient all-reduce)
+        eps = torch.randn(K, 4, device=dev, generator=g) if world == 1 else None
+        sc = tr.step(PS.H, PS.W, PS.FOCAL, rays, target.contiguous(), t_rand=torch.rand(n, S, device=dev, generator=g), eps=eps,
+                     near=PS.NEAR, far=PS.FAR, ndc=False)
+        if it in marks and rank == 0:
             curve[it] = PS.held_out_psnr(net, poses, images, i_test, dev)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    out = {"scene": PS.LABEL, "what": "held-out PSNR of the K-mean prediction, mse2psnr(img2mse(mean_K rgb_map, target)) as RUN:1027-1029",
-           "views": f"{len(i_train)} train / {len(i_test)} held out, {PS.H}x{PS.W}", "N_rand": n_rand, "K": K, "W": 256, "steps": steps,
-           "held_out_psnr_db_by_step": {str(k): round(v, 3) for k, v in curve.items()}, "value": round(curve[steps], 3), "unit": "dB",
-           "train_batch_psnr_db_last_step": round(float(sc[3]), 3), "wall_s_incl_eval": round(wall, 2),
-           "lrate": 5e-4, "lrate_decay": 250, "beta1": 0.01, "precision": "fp32"}
+    out = None
+    if rank == 0:
+        out = {"scene": PS.LABEL, "what": "held-out PSNR of the K-mean prediction, mse2psnr(img2mse(mean_K rgb_map, target)) as RUN:1027-1029",
+               "views": f"{len(i_train)} train / {len(i_test)} held out, {PS.H}x{PS.W}", "N_rand": n_rand, "n_gpus": world,
+               "global_batch": n_rand * world, "K": K, "W": 256, "steps": steps, "epochs_crossed": pool.epoch,
+               "feeder": "RayPool" + (f"(rank, world={world}): one permutation per epoch for all ranks ({pool.sync}), rank r takes rows "
+                                      f"[i + r N_rand, i + (r+1) N_rand) of the step's window" if world > 1 else ""),
+               "held_out_psnr_db_by_step": {str(k): round(v, 3) for k, v in curve.items()}, "value": round(curve[steps], 3), "unit": "dB",
+               "train_batch_psnr_db_last_step": round(float(sc[3]), 3), "wall_s_incl_eval": round(wall, 2),
+               "lrate": 5e-4, "lrate_decay": 250, "beta1": 0.01, "precision": "fp32", "note": PSNR_NOTE}
     net.release_workspace()
+    return out
+
+
+def psnr_vs_single_process(dev, rank, world, barrier, steps=25, n_rand=1024, K=4, tol_db=0.05):
+    """Pass/fail at N > 1: the N-rank run (sharded pool, gradient all-reduce) reproduces ONE process training the same global batches -
+    same initial weights, same permutation (seed form of the pool), the same jitter row for every ray and the same latents every step;
+    their held-out PSNR after `steps` steps must agree within `tol_db` (what differs is the summation order of the gradient)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import procedural_scene as PS
+    import cfnerf_amd
+    from cfnerf_amd import train as T
+    poses, images, i_train, i_test = PS.make(dev)
+
+    def run(r, w, nr):
+        net = _psnr_net(dev, K)
+        pool = cfnerf_amd.RayPool(images, poses, PS.H, PS.W, PS.FOCAL, i_train, nr, rank=r, world=w, seed=11, sync="seed")
+        tr = T.Trainer(net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=w)
+        gj, ge = torch.Generator().manual_seed(12), torch.Generator().manual_seed(13)
+        for _ in range(steps):
+            rays, target = pool.next_batch()
+            n = rays.shape[1]
+            t_all = torch.rand(n * w, S, generator=gj)              # jitter of the GLOBAL batch; a rank keeps its rows
+            eps = torch.randn(K, 4, generator=ge)
+            tr.step(PS.H, PS.W, PS.FOCAL, rays, target.contiguous(), t_rand=t_all[r * n:(r + 1) * n].to(dev), eps=eps.to(dev),
+                    near=PS.NEAR, far=PS.FAR, ndc=False)
+        ps = PS.held_out_psnr(net, poses, images, i_test, dev) if r == 0 else None
+        flat = net.flat.detach().clone()
+        net.release_workspace()
+        return ps, flat, pool.epoch
+
+    p_multi, flat_multi, ep = run(rank, world, n_rand)
+    out = None
+    if rank == 0:
+        p_single, flat_single, _ = run(0, 1, n_rand * world)
+        dw = float((flat_multi - flat_single).abs().max() / flat_single.abs().max())
+        out = {"what": f"{world}-rank run (sharded RayPool, gradient all-reduce) vs ONE process on the same global batches of {n_rand * world} rays: "
+                       f"same weights / permutation / jitter / latents for {steps} steps; held-out PSNR of both",
+               "psnr_db_ranks": p_multi, "psnr_db_single_process": p_single, "abs_psnr_diff_db": abs(p_multi - p_single),
+               "max_abs_param_diff_rel": dw, "epochs_crossed": ep, "tolerance_db": tol_db, "agree": bool(abs(p_multi - p_single) <= tol_db)}
+    barrier()                                   # the other ranks wait here while rank 0 trains the one-process run
     return out
 
 
@@ -514,10 +590,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if force_dist and "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1")
-        if same_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # a run that cannot be what --gpus asked for ends HERE with one line and a non-zero code, not with a number for fewer GPUs
+        backend = "gloo" if same_gpu else "nccl"
+        try:
+            if same_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+        except Exception as e:
+            print(f"bench.py: rank {rank}: init_process_group({backend!r}) failed: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        if dist.get_world_size() != (args.gpus if world > 1 else 1):
+            print(f"bench.py: rank {rank}: the {backend} group spans {dist.get_world_size()} rank(s), --gpus asked for {args.gpus}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     from cfnerf_amd import train as T
     if not T.backward_available():
@@ -539,9 +625,30 @@ def main():
         return float(t.item())
 
     step_ms = []
-    dt = max_over_ranks(timed(wl, args.steps, args.warmup, sync, step_ms))
+    dt_own = timed(wl, args.steps, args.warmup, sync, step_ms)
+    dt = max_over_ranks(dt_own)
     # duration of the dominant kernel: mean over the launches of the timed region, HIP events on the launch stream
     fwd_ms = wl.fwd_mean_ms(args.steps)
+    # N > 1: what the exchange exposed on the compute stream during the timed steps (this rank), then ONE more all-reduce (MAX of
+    # [x, -x] pairs) for the spread over the ranks of the step time, the forward kernel and the exposed exchange
+    comm, skew = None, None
+    if dist is not None and mode == "train" and name != "C5":
+        comm = wl.trainer.comm_stats(args.steps)
+        own = [dt_own / args.steps * 1e3, fwd_ms, comm.get("exposed_ms_mean", 0.0), comm.get("exposed_ms_max", 0.0)]
+        t = torch.tensor([v for x in own for v in (x, -x)], device="cpu" if same_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = t.tolist()
+        skew = {"ms_per_step_max": t[0], "ms_per_step_min": -t[1], "fwd_launch_ms_max": t[2], "fwd_launch_ms_min": -t[3],
+                "what": "over the ranks: each rank's own wall time per step of the timed region (between the same two barriers) and its mean "
+                        "fused-forward launch duration"}
+        comm.update(exposed_ms_mean_max_over_ranks=t[4], exposed_ms_mean_min_over_ranks=-t[5], exposed_ms_max_over_ranks=t[6],
+                    what="gradient exchange of one train step (flat gradient + 4 K_max latents tail): time between two HIP events recorded on the "
+                         "compute stream right before and right after Trainer._exchange, i.e. what the exchange EXPOSES there (the compute "
+                         "stream waits for the collective); rank 0's mean / max / min over the timed steps, then the spread of the means over ranks",
+                    frac_of_step=comm.get("exposed_ms_mean", 0.0) / (dt / args.steps * 1e3),
+                    overlap_comm_pays_if="exposed_ms_mean > ~0.15 ms: the two-bucket form costs ~0.13 ms of gathers / scatters / a second "
+                                         "launch per step (measured on one GPU) and can hide at most the early bucket's ~3/4 of the payload "
+                                         "under the last ~0.2 ms of the backward (CFNERF_BENCH_OVERLAP=1 measures it)")
     kms = wl.kernel_ms(sync)
     extras = world == 1 and not args.no_alt and name == "C2" and args.precision == "fp32" and mode == "train"
 
@@ -626,8 +733,23 @@ def main():
         wh.net.release_workspace()
         del wh
 
-    # PSNR, the second half of the headline metric, on the synthetic stand-in scene (one GPU, default train run only)
-    psnr = psnr_block(dev, args.psnr_steps) if extras and args.psnr_steps > 0 else None
+    # PSNR, the second half of the headline metric, on the synthetic stand-in scene - at EVERY GPU count (default train run only): one rank
+    # trains 1024-ray batches, N ranks train world x 1024-ray global batches through the sharded ray pool + the Trainer's all-reduce.
+    # Nothing here may take the headline line down with it: a failure is reported inside the psnr object.
+    psnr = None
+    if not args.no_alt and name == "C2" and args.precision == "fp32" and mode == "train" and args.psnr_steps > 0 and not force_dist:
+        wl.__dict__.pop("trainer", None)
+        wl.net.release_workspace()
+        try:
+            psnr = psnr_block(dev, args.psnr_steps, rank=rank, world=world)
+        except Exception as e:
+            if world > 1:
+                raise                          # a rank that fell out of a collective cannot be papered over
+            psnr = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            vs = psnr_vs_single_process(dev, rank, world, sync)
+            if rank == 0:
+                psnr["vs_single_process"] = vs
 
     out = None
     if rank == 0:
@@ -635,7 +757,7 @@ def main():
         fl = wl.fwd_flops()                     # forward GEMM FLOPs of one launch of the fused forward kernel
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
         traffic, mfma_busy, src = None, None, None
-        for prof in ("r03_traffic.json", "r02_traffic.json"):
+        for prof in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     tj = json.load(f)[f"{name}:{mode}"]
@@ -685,13 +807,9 @@ def main():
             out["stress_w512"] = stress
         if hier is not None:
             out["alt_config"] = hier
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mode, wl.cfg)
-            if psnr is not None:
-                wl.__dict__.pop("trainer", None)
-                wl.net.release_workspace()
-                psnr["vs_oracle"] = psnr_oracle_agreement(dev)
-                psnr["vs_reference_run"] = psnr_reference_run_agreement()
+        if comm is not None:
+            out["comm"] = comm
+            out["rank_skew"] = skew
 
     # the JSON line is the LAST thing on stdout: RCCL prints its version banner through libc's buffered stdout (it would
     # otherwise surface at process exit, after the line), so every rank flushes that before the final barrier
@@ -707,6 +825,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
+    # the CPU leg - at every N, on rank 0, AFTER the final barrier (the other ranks are done; nothing waits in a collective while the host
+    # cores are timed): the oracle as the CPU baseline and as the checker of the two PSNR agreements.  A failure in here is reported
+    # inside the object it belongs to; the headline line is printed regardless.
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(mode, wl.cfg)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if psnr is not None and psnr.get("value") is not None:
+            wl.__dict__.pop("trainer", None)
+            wl.net.release_workspace()
+            for key, fn in (("vs_oracle", lambda: psnr_oracle_agreement(dev)), ("vs_reference_run", psnr_reference_run_agreement)):
+                try:
+                    psnr[key] = fn()
+                except Exception as e:
+                    psnr[key] = {"agree": None, "error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
 

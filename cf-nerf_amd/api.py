@@ -343,6 +343,11 @@ class NeRF_Flows(nn.Module):
     def mark_dirty(self):
         """Call after writing into ``flat.data`` / ``view(key)`` directly."""
         self._dirty = True
+        self.params_serial += 1
+
+    # bumped by every parameter update that does not go through a torch in-place op on ``flat`` (the fused Adam kernel of
+    # train.Trainer writes through the raw pointer; mark_dirty): with ``flat._version`` it identifies "the weights of a forward"
+    params_serial = 0
 
     @property
     def handle(self):
@@ -467,12 +472,22 @@ class _NetworkFn(torch.autograd.Function):
         ent = torch.zeros(1, device=xf.device)
         ctx.generation = _NetworkFn._forward_stash(model, xf, eps, raw, ent)
         ctx.model, ctx.xf, ctx.eps, ctx.n_params = model, xf, eps, flat.numel()
+        ctx.params_at = (flat._version, model.params_serial)       # the weights this graph was taken at
         return raw, ent.reshape(())
 
     @staticmethod
     def backward(ctx, d_raw, d_ent):
         model, lib = ctx.model, L.lib()
         if lib.cfnerf_model_stash_generation(model.handle) != ctx.generation:
+            # the stash is gone: re-run the forward - which is only the SAME forward if the parameters are the ones it was taken at
+            # (torch autograd raises in this situation: an optimizer.step between the chunk backwards, a retained graph reused
+            # after an update; differentiating at the current weights instead would be silently wrong)
+            if (model.flat._version, model.params_serial) != ctx.params_at or getattr(model, "_dirty", False):
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: the "
+                                   "parameters of NeRF_Flows changed between this forward and its backward, and a later grad-enabled forward "
+                                   "has replaced the model's one activation stash, so the forward cannot be re-run at the weights the graph "
+                                   "was taken at (call backward() before optimizer.step(), or run one chunk per step)")
+            model._sync()
             P, K = ctx.xf.shape[0], ctx.eps.shape[0]
             ctx.generation = _NetworkFn._forward_stash(model, ctx.xf, ctx.eps, torch.empty(P, K, 4, device=ctx.xf.device),
                                                        torch.zeros(1, device=ctx.xf.device))

@@ -27,7 +27,7 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(CFNERF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" void cfnerf_set_error_(const char* msg) {      // used by the other translation units
+extern "C" void cfnerf_set_error_(const char* msg) {      // used by the other translation units; hidden (not exported)
     std::snprintf(g_err, sizeof g_err, "%s", msg);
 }
 
@@ -446,15 +446,15 @@ float cfnerf_timing_last_ms(cfnerf_model* m, int which) {
 
 }  // extern "C"
 
-// ---- debug / test helpers (not part of include/cfnerf.h) ------------------------------------------
+// ---- test hooks (NOT part of the ABI of include/cfnerf.h; declared in tests/cfnerf_debug.h) -------------------
 extern "C" {
 // host-side packing with the same index map the device kernel uses (CPU tests of the operand layout)
-int64_t cfnerf_debug_packed_floats(const cfnerf_cfg* cfg) {
+CFNERF_API int64_t cfnerf_debug_packed_floats(const cfnerf_cfg* cfg) {
     if (!cfg || validate_cfg(*cfg)) return -1;
     ParamLayout L = build_layout(*cfg);
     return build_pack_plan(*cfg, L).tab.packed_floats;
 }
-int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float* packed_host) {
+CFNERF_API int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float* packed_host) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);
     PackPlan P = build_pack_plan(*cfg, L);
@@ -470,7 +470,7 @@ int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float*
     return CFNERF_OK;
 }
 // copy a stash / backward-workspace buffer of the last STASH forward into dst (device), for tests
-int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s) {
+CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s) {
     if (!m || !m->stash.valid) return -1;
     Stash& q = m->stash;
     const int W = m->cfg.netwidth;
@@ -497,7 +497,7 @@ int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, fl
     return cnt;
 }
 // operand table entry by name: out[4] = {w_off, b_off, kc, nt}
-int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
+CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);
     PackPlan P = build_pack_plan(*cfg, L);

@@ -545,30 +545,54 @@ __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const Epi
     else                  store_bwd_impl<NTW, PREC, true>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
 }
 
+// the kernarg segment of bwd_data_kernel as one struct (see fused_fwd_kernel)
+struct BwdKargs { BwdArgs A; NetTab T; };
+static_assert(offsetof(BwdKargs, T) == (sizeof(BwdArgs) + alignof(NetTab) - 1) / alignof(NetTab) * alignof(NetTab), "kernarg layout");
+
 template <int W, int PREC>
 __global__ __launch_bounds__(kThreads, (W <= 256) ? 2 : 1)
-void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scalar loads from the kernarg segment (see fused_fwd_kernel)
+void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
+    // arguments: scalar loads from the kernarg segment, fetched per phase (CFN_PHASE_ARGS; see fused_fwd_kernel and kernarg_fresh)
+#define CFN_PHASE_LOCALS(F)                                                                                                  \
+    [[maybe_unused]] const int HA = F(HA0), HR = F(HR0), HLD = HA + 4, D = F(D0), wave = F(wave0), Sn = F(Sn0);               \
+    [[maybe_unused]] const float* __restrict__ const wp = F(wp0);                                                              \
+    [[maybe_unused]] const __bf16* __restrict__ const wp16 = F(wp160);                                                         \
+    [[maybe_unused]] const int64_t P = F(P0), n_tiles = F(n_tiles0);                                                           \
+    [[maybe_unused]] float* const dbp = F(dbp0);                 /* this workgroup's bias-gradient partials */                 \
+    [[maybe_unused]] const uint32_t* const mb_all = F(mb_all0)
+#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3: 222 spilt SGPRs at W = 256)
+    const BwdArgs& A = A_; const NetTab& T = T_;
+#define CFN_KEEP(x) (x)
+#define CFN_PHASE_ARGS CFN_PHASE_LOCALS(CFN_KEEP)
+#else
+    (void)A_; (void)T_;
+#define CFN_KARGS const CFN_KCONST BwdKargs* kq_ = kernarg_fresh<BwdKargs>(); const CFN_KCONST BwdArgs& A = kq_->A; const CFN_KCONST NetTab& T = kq_->T
+#define CFN_PHASE_ARGS CFN_KARGS; CFN_PHASE_LOCALS(sgpr_fresh)
+    CFN_KARGS;
+#endif
     constexpr int LD = act_ld(W);
     constexpr int NT = W / 32, NTW = (NT + kWaves - 1) / kWaves, NTV = (W / 64 + kWaves - 1) / kWaves;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HA = T.ha_sz, HR = T.hr_sz, HLD = HA + 4, D = T.D;
-    float* act = smem;
-    float* hs = act + kTileM * LD;
-    const int tid = threadIdx.x, wave = wave_id();
-    const float* __restrict__ wp = A.wp;
-    const __bf16* __restrict__ wp16 = reinterpret_cast<const __bf16*>(A.wp16);
-    const int64_t P = A.P;
-    float* dbp = A.dbp + (size_t)blockIdx.x * A.nb;           // this workgroup's bias-gradient partials
-    const int64_t n_tiles = A.n_tiles;
-    const int cpr = (A.S + kTileM - 1) / kTileM;                // chunks per ray: the forward's tiling
+    const int HA0 = T.ha_sz, HR0 = T.hr_sz, D0 = T.D;
+    float* const act = smem;
+    float* const hs = act + kTileM * LD;
+    const int tid = threadIdx.x, wave0 = wave_id();
+    const float* const wp0 = A.wp;
+    const __bf16* const wp160 = reinterpret_cast<const __bf16*>(A.wp16);
+    const int64_t P0 = A.P;
+    float* const dbp0 = A.dbp + (size_t)blockIdx.x * A.nb;
+    const int64_t n_tiles0 = A.n_tiles;
     constexpr int kMbStride = (W / 32) * 64;
-    const uint32_t* mb_all = A.mbits;
+    const uint32_t* const mb_all0 = A.mbits;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int Sn0 = A.S;
+    for (int64_t tile = blockIdx.x; tile < n_tiles0; tile += gridDim.x) {
+        CFN_PHASE_ARGS;
+        const int cpr = (Sn + kTileM - 1) / kTileM;             // chunks per ray: the forward's tiling
         const int64_t ray = tile / cpr;
         const int chunk = (int)(tile - ray * cpr);
-        const int64_t p0 = ray * (int64_t)A.S + (int64_t)chunk * kTileM;
-        const int rows_valid = min(kTileM, A.S - chunk * kTileM);
+        const int64_t p0 = ray * (int64_t)Sn + (int64_t)chunk * kTileM;
+        const int rows_valid = min(kTileM, Sn - chunk * kTileM);
         // ---- 0. g_theta tile -> act[:, 0:128)
         for (int idx = tid; idx < kTileM * (kThetaAll / 4); idx += kThreads) {
             const int row = idx >> 5, q = idx & 31;
@@ -592,29 +616,31 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
         }
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
         if (T.bt_fr.nt > 2 || T.bt_fa.nt > 2) {
+            CFN_PHASE_ARGS;
             // h sizes of 96 / 128 (3 - 4 n-tiles per head): every wave takes n-tile `wave` of BOTH heads, one after the other
             f32x16 accR[2][1], accA[2][1];
             EpiPre<1> eR, eA;
             acc_zero(accR); acc_zero(accA);
             epi_prefetch<1>(eR, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
             epi_prefetch<1>(eA, T.bt_fa.nt, wave, kWaves, nullptr, dbp + A.db_ha);
-            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accR, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
-            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, T.bt_fa, wave, kWaves, wp, wp16, act, LD, kThetaRgb);
+            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accR, kload(T.bt_fr), wave, kWaves, wp, wp16, act, LD);
+            mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, kload(T.bt_fa), wave, kWaves, wp, wp16, act, LD, kThetaRgb);
             __syncthreads();
             store_bwd<1, PREC>(accR, eR, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
             store_bwd<1, PREC>(accA, eA, T.bt_fa.nt, wave, kWaves, hs, HLD, A.g_ha + p0 * HA, HA, dbp + A.db_ha, rows_valid);
             __syncthreads();
         } else {
+            CFN_PHASE_ARGS;
             f32x16 acc[2][1];
             EpiPre<1> e;
             acc_zero(acc);
             const bool is_rgb = wave < 2;
             if (is_rgb) {
                 epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
-                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fr, wave, kWaves, wp, wp16, act, LD);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_fr), wave, kWaves, wp, wp16, act, LD);
             } else {
                 epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
-                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_fa, wave - 2, kWaves, wp, wp16, act, LD, kThetaRgb);
+                mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_fa), wave - 2, kWaves, wp, wp16, act, LD, kThetaRgb);
             }
             __syncthreads();
             if (is_rgb) store_bwd<1, PREC>(acc, e, T.bt_fr.nt, wave, kWaves, act, LD, A.g_hr + p0 * HR, HR, dbp + A.db_hr, rows_valid);
@@ -623,34 +649,37 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
         }
         // ---- 2. dv = (dh_rgb * R) . relu'(v)
         {
+            CFN_PHASE_ARGS;
             f32x16 acc[2][NTV];
             EpiPre<NTV> e;
             acc_zero(acc);
             epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v);
-            mma_any<NTV, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_hr, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTV, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_hr), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
             __syncthreads();
         }
         // ---- 3. dfeature = dv * V[:, 0:W]        (feature_linear has no activation, MOD:176)
         {
+            CFN_PHASE_ARGS;
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat);
-            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_vf, wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_vf), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
             __syncthreads();
         }
         // ---- 4. dh_{D-1} = (dfeature * F + dh_alpha * A) . relu'(h_{D-1})
         {
+            CFN_PHASE_ARGS;
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W);
-            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_ft, wave, kWaves, wp, wp16, act, LD);
-            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_ha, wave, kWaves, wp, wp16, hs, HLD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ft), wave, kWaves, wp, wp16, act, LD);
+            mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ha), wave, kWaves, wp, wp16, hs, HLD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
             __syncthreads();
@@ -665,23 +694,28 @@ void bwd_data_kernel(const BwdArgs A, const NetTab T) {      // T by value: scal
         constexpr bool kBPre = PREC == PREC_F32 && W <= 256;
 #endif
         f32x4 bpre[NTW];
-        if (kBPre) b_prefetch<NTW>(T.bt_trunk[D - 1], wave, kWaves, wp, bpre);
+        if (kBPre) b_prefetch<NTW>(kload(T.bt_trunk[D - 1]), wave, kWaves, wp, bpre);
         for (int l = D - 1; l >= 1; --l) {
+            CFN_PHASE_ARGS;
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
             epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
             if (kBPre) {
-                mma_seg_pre<NTW>(acc, T.bt_trunk[l], wave, kWaves, wp, act, LD, bpre);
-                if (l > 1) b_prefetch<NTW>(T.bt_trunk[l - 1], wave, kWaves, wp, bpre);
+                mma_seg_pre<NTW>(acc, kload(T.bt_trunk[l]), wave, kWaves, wp, act, LD, bpre);
+                if (l > 1) b_prefetch<NTW>(kload(T.bt_trunk[l - 1]), wave, kWaves, wp, bpre);
             } else {
-                mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, T.bt_trunk[l], wave, kWaves, wp, wp16, act, LD);
+                mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_trunk[l]), wave, kWaves, wp, wp16, act, LD);
             }
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
             __syncthreads();
         }
     }
+#undef CFN_PHASE_ARGS
+#undef CFN_PHASE_LOCALS
+#undef CFN_KARGS
+#undef CFN_KEEP
 }
 
 // ================================================================================================
@@ -1678,7 +1712,7 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
 // ---- debug / test helper (not part of include/cfnerf.h): the weight-gradient tile plan of a configuration, for the
 // CPU test that every weight element is covered exactly once.  16 int32 per tile:
 // {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[0..3], dst_ld, dst_col, 0, 0} followed by 4 uint32 seg_dst in a second array.
-extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
+extern "C" CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);
     Stash q;                                   // fake, distinct operand bases: only the geometry is reported
@@ -1705,7 +1739,7 @@ extern "C" int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
 // the blocks of that plan for a given point count and CU count: 5 int64 per block {kind (0: 2 x 4, 1: 1 x 8, 2: small job), tile, split,
 // pb, pe}; tile indices refer to the order cfnerf_debug_dw_plan reports (big tiles, then small tiles); plus per tile its nsplit and, per
 // parameter tensor, the slot count of the reduction.
-extern "C" int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
+extern "C" CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
                                       int32_t* seg_nsplit, int max_segs) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);

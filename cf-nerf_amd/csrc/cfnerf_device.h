@@ -26,6 +26,36 @@ __device__ __forceinline__ int lane_id_opaque() {
 }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// ---- the kernel arguments as MEMORY, fetched per phase, not as registers held across the persistent tile loop -------------------
+// The fused kernels take ~1.2 KB of arguments (the pointer block + the 960-byte operand table).  Read as by-value parameters, every
+// field a tile touches - and every predicate / address the optimiser derives from one - is loop-invariant, so it is hoisted in front of
+// the persistent loop: ~300 scalars for ~100 SGPRs, the rest spilt to VGPR lanes (v_writelane) and fetched back with ~550 v_readlane
+// per (tile, wave) - vector-pipe instructions, which on this chip come straight out of the MFMA issue slots.  Instead a PHASE (a trunk
+// layer, the heads, the flows ...) takes a pointer to the kernarg segment that the optimiser cannot see through and s_loads what it
+// needs from the constant cache: scalar-unit work under the phase's first MFMAs, nothing live across phases.
+#define CFN_KCONST __attribute__((address_space(4)))
+template <class KA>
+__device__ __forceinline__ const CFN_KCONST KA* kernarg_fresh() {
+    const CFN_KCONST KA* p = (const CFN_KCONST KA*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// a wave-uniform value (an SGPR or an SGPR pair) the optimiser cannot see through from here on
+template <class V>
+__device__ __forceinline__ V sgpr_fresh(V v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// by-value copy of a table entry out of the kernarg segment (scalar loads)
+template <class V>
+__device__ __forceinline__ V kload(const CFN_KCONST V& src) {
+    V r;
+    __builtin_memcpy(&r, &src, sizeof(V));
+    return r;
+}
+template <class V>
+__device__ __forceinline__ V kload(const V& src) { return src; }
+
 // activation row stride (floats): +4 keeps ds_read_b128 of 16 consecutive rows conflict-free
 // (row stride = 16 B mod 256 B) and rows 16-B aligned.  >= 128 so the theta tile fits.
 __host__ __device__ constexpr int act_ld(int W) { return (W > kThetaAll ? W : kThetaAll) + 4; }

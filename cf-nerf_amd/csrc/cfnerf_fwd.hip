@@ -85,36 +85,58 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
 
 #ifdef CFN_TIMESTAMP
 __device__ unsigned long long g_dbg[4096];     // [0,2048): per-WG start/end/placement; [2048,..): per-layer marks of WG 0 and WG grid/2
-extern "C" int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
+extern "C" CFNERF_API int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
 }
 #endif
 
+// the kernarg segment of fused_fwd_kernel as one struct (second argument at the first argument's size rounded up to its own alignment)
+struct FwdKargs { FwdArgs A; NetTab T; };
+static_assert(offsetof(FwdKargs, T) == (sizeof(FwdArgs) + alignof(NetTab) - 1) / alignof(NetTab) * alignof(NetTab), "kernarg layout");
+
 template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
 __global__ __launch_bounds__(FwdCfg<W>::NTHR, 2)
-void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
-    // T by value: it lives in the kernarg segment, so every per-layer descriptor read is a scalar load from constant
-    // memory.  Through a global pointer the compiler must assume the kernel's own stores may alias it and issues VECTOR
-    // loads with a full wait in front of each layer's first operand fetch (two or three dependent L2 round trips).
+void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
+    // The arguments live in the kernarg segment, so every per-layer descriptor read is a scalar load from constant
+    // memory.  (Through a global pointer the compiler must assume the kernel's own stores may alias the table and issues
+    // VECTOR loads with a full wait in front of each layer's first operand fetch: two or three dependent L2 round trips.)
+    // They are read PER PHASE through CFN_PHASE_ARGS (kernarg_fresh, cfnerf_device.h), not held in registers across the tile loop.
+    // The few scalars every phase needs (sizes, the wave index, the operand pointers) stay in SGPRs, but a phase takes them through
+    // sgpr_fresh: what the optimiser DERIVES from them (row offsets rr * HR * 4 of a slab store, wave * 32, LDS sub-pointers ...) is then
+    // recomputed on the scalar unit inside the phase instead of being hoisted in front of the tile loop and spilt as well.
+#define CFN_PHASE_LOCALS(F)                                                                                                              \
+    [[maybe_unused]] const int HA = F(HA0), HR = F(HR0), HLD = HA + 4, S = F(S0), K = F(K0), ic = F(ic0), icv = F(icv0), wave = F(wave0);  \
+    [[maybe_unused]] const int chunks_per_ray = (S + kTileM - 1) / kTileM, Dn = F(Dn0), skip_l = F(skip0);                                \
+    [[maybe_unused]] float* const rowinfo = hs + kTileM * HLD; /* [65][4]: x y z zval */                                                  \
+    [[maybe_unused]] float* const gdir = rowinfo + 68 * 4;     /* [32] */                                                                 \
+    [[maybe_unused]] float* const red = gdir + 32;             /* [16] */                                                                 \
+    [[maybe_unused]] float* const comp = red + 16;             /* [comp_rows(K)][8]: r g b depth acc T disp _ */                          \
+    [[maybe_unused]] const float* __restrict__ const wp = F(wp0);                                                                          \
+    [[maybe_unused]] const __bf16* __restrict__ const wp16 = F(wp160)
+#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3: 289 spilt SGPRs in the W = 256 train variant)
+    const FwdArgs& A = A_; const NetTab& T = T_;
+#define CFN_KEEP(x) (x)
+#define CFN_PHASE_ARGS CFN_PHASE_LOCALS(CFN_KEEP)
+#else
+    (void)A_; (void)T_;
+#define CFN_KARGS const CFN_KCONST FwdKargs* kq_ = kernarg_fresh<FwdKargs>(); const CFN_KCONST FwdArgs& A = kq_->A; const CFN_KCONST NetTab& T = kq_->T
+#define CFN_PHASE_ARGS CFN_KARGS; CFN_PHASE_LOCALS(sgpr_fresh)
+    CFN_KARGS;
+#endif
     using C = FwdCfg<W>;
     constexpr int LD = C::LD;
     constexpr int kWv = C::NWV, kThr = C::NTHR;     // waves / threads of this width's workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HA = T.ha_sz, HR = T.hr_sz;
-    const int HLD = HA + 4;
-    float* act = smem;
-    float* hs = act + kTileM * LD;
-    float* rowinfo = hs + kTileM * HLD;       // [65][4]: x y z zval
-    float* gdir = rowinfo + 68 * 4;           // [32]
-    float* red = gdir + 32;                   // [16]
-    float* comp = red + 16;                   // [comp_rows(K)][8]: r g b depth acc T disp _
+    const int HA0 = T.ha_sz, HR0 = T.hr_sz;
+    float* const act = smem;
+    float* const hs = act + kTileM * LD;      // then rowinfo | gdir | red | comp: CFN_PHASE_LOCALS
 
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const float* __restrict__ wp = A.wp;
-    const __bf16* __restrict__ wp16 = reinterpret_cast<const __bf16*>(A.wp16);
-    const int S = A.S, K = A.K;
-    const int ic = T.ic, icv = T.icv;
-    const int chunks_per_ray = (S + kTileM - 1) / kTileM;
+    const int tid = threadIdx.x, lane = lane_id(), wave0 = wave_id();
+    const float* const wp0 = A.wp;
+    const __bf16* const wp160 = reinterpret_cast<const __bf16*>(A.wp16);
+    const int S0 = A.S, K0 = A.K;
+    const int ic0 = T.ic, icv0 = T.icv;
+    const int Dn0 = T.D, skip0 = T.skip;
     const int64_t n_units = (MODE == 0) ? A.N : (A.P + kTileM - 1) / kTileM;
 
     float ent_r_sum = 0.f, ent_a_sum = 0.f;   // per-lane partial sums of the log-det terms (TRAIN)
@@ -139,6 +161,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
 #endif
     for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         float ro[3], rd[3], nearv = 0.f, farv = 1.f, dnorm = 0.f;
+        CFN_PHASE_ARGS;
         if (MODE == 0) {
             const float* r = A.rays + unit * 11;
 #pragma unroll
@@ -155,6 +178,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
         }
         const int n_chunks = (MODE == 0) ? chunks_per_ray : 1;
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            CFN_PHASE_ARGS;
             // global point index of row 0 and number of valid rows of this tile
             const int64_t p0 = (MODE == 0) ? unit * (int64_t)S + (int64_t)chunk * kTileM : unit * (int64_t)kTileM;
             const int rows_valid = (MODE == 0) ? min(kTileM, S - chunk * kTileM) : (int)min((int64_t)kTileM, A.P - p0);
@@ -199,7 +223,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             // hold them before a layer's first MFMA, so a fetch at the top of the layer is an exposed L2 round trip per layer):
             // layer 0's rides under the encoding, layer l+1's under layer l's MFMAs, and so on down the heads.
             float bias_n[C::NTW];
-            load_bias<C::NTW>(T.trunk[0], wave, kWv, wp, bias_n);
+            load_bias<C::NTW>(kload(T.trunk[0]), wave, kWv, wp, bias_n);
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             // gamma(p) is needed again at the skip layer, five layers later, when the in-place tile has long been overwritten.
@@ -245,14 +269,15 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
 
             CFN_MARK();                              // encoding done
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
-            for (int l = 0; l < T.D; ++l) {
+            for (int l = 0; l < Dn; ++l) {
+                CFN_PHASE_ARGS;
                 f32x16 acc[2][C::NTW];
                 acc_init(acc, bias_n);
-                load_bias<C::NTW>((l + 1 < T.D) ? T.trunk[l + 1] : T.ft, wave, kWv, wp, bias_n);     // next layer's / the feature head's
+                load_bias<C::NTW>(kload((l + 1 < Dn) ? T.trunk[l + 1] : T.ft), wave, kWv, wp, bias_n);     // next layer's / the feature head's
                 CFN_MARK();                          // MFMA phase of layer l starts
-                mma_any<C::NTW, PREC, 2>(acc, T.trunk[l], wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(acc, kload(T.trunk[l]), wave, kWv, wp, wp16, act, LD);
                 CFN_MARK();                          // ... ends for wave 0
-                if (l >= 1 && l - 1 == T.skip) {
+                if (l >= 1 && l - 1 == skip_l) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
                     if (kParkRegs) {                 // act[:, 0:64) <- gamma(p) again, from the registers it was kept in
 #pragma unroll
@@ -274,14 +299,14 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                         encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
                     }
                     __syncthreads();
-                    mma_any<C::NTW, PREC, 2>(acc, T.skipseg, wave, kWv, wp, wp16, act, LD);
+                    mma_any<C::NTW, PREC, 2>(acc, kload(T.skipseg), wave, kWv, wp, wp16, act, LD);
                 }
                 __syncthreads();
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, T.trunk[l], wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, kload(T.trunk[l]), wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
                 if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
@@ -293,12 +318,13 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             //         h is dead, instead of one wave grinding through the whole K while three wait.
             float bias_v[C::NTV];                    // views-layer bias, in flight during the heads
             {
+                CFN_PHASE_ARGS;
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
                 acc_init(accF, bias_n); acc_zero(accA);
-                load_bias<C::NTV>(T.vf, wave, kWv, wp, bias_v);
-                mma_ksplit<PREC, 2>(accA, T.ha, wave, kWv, wp, wp16, act, LD);
-                mma_any<C::NTW, PREC, 2>(accF, T.ft, wave, kWv, wp, wp16, act, LD);
+                load_bias<C::NTV>(kload(T.vf), wave, kWv, wp, bias_v);
+                mma_ksplit<PREC, 2>(accA, kload(T.ha), wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(accF, kload(T.ft), wave, kWv, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
                 {
                     const int lo = lane_id_opaque();
@@ -323,7 +349,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 }
                 __syncthreads();
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, T.ft, wave, kWv, wp, act, LD, 0,
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, kload(T.ft), wave, kWv, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
                 if (kRows && A.st_feat != nullptr) stash_rows<W, kThr>(act, LD, A.st_feat + p0 * W, rows_valid);
@@ -332,10 +358,11 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
             float bias_h[1];                         // h_rgb bias, in flight during the views layer
             {
+                CFN_PHASE_ARGS;
                 f32x16 acc[2][C::NTV];
                 acc_init(acc, bias_v);
-                load_bias<1>(T.hr, wave, kWv, wp, bias_h);
-                mma_any<C::NTV, PREC, 2>(acc, T.vf, wave, kWv, wp, wp16, act, LD);
+                load_bias<1>(kload(T.hr), wave, kWv, wp, bias_h);
+                mma_any<C::NTV, PREC, 2>(acc, kload(T.vf), wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThr) {
                     const int row = idx >> 5, c = idx & 31;
@@ -346,11 +373,11 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                     if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
-                mma_any<C::NTV, PREC, 2>(acc, T.vd, wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, 2>(acc, kload(T.vd), wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, T.vf, wave, kWv, wp, act, LD, 0,
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, kload(T.vf), wave, kWv, wp, act, LD, 0,
                                                     A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
                 if (kRows && A.st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, A.st_v + p0 * (W / 2), rows_valid);
@@ -358,11 +385,12 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             CFN_MARK();                              // views done
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
+                CFN_PHASE_ARGS;
                 f32x16 acc[2][1];
                 acc_init(acc, bias_h);
-                mma_any<1, PREC, 2>(acc, T.hr, wave, kWv, wp, wp16, act, LD);
+                mma_any<1, PREC, 2>(acc, kload(T.hr), wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, T.hr, wave, kWv, wp, act, LD, W / 2,
+                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, kload(T.hr), wave, kWv, wp, act, LD, W / 2,
                                          A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
@@ -370,13 +398,14 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             // ---- 7. amortised flow parameters (MOD:366-383), once per point (the reference recomputes
             //         them K times on duplicated rows, MOD:210-217): theta -> act[:, 0:128)
             {
+                CFN_PHASE_ARGS;
                 f32x16 acc[2][1];
                 acc_zero(acc);
                 const bool is_rgb = wave < 3;               // waves 0-2: the three rgb n-tiles; wave 3: alpha; others idle
                 const bool is_theta = wave < 4;
                 const float bv = wp[(is_rgb ? T.fr.b_off + wave * 32 : T.fa.b_off) + (lane_id_opaque() & 31)];   // lands under the MFMAs
-                if (is_rgb)        mma_any<1, PREC, 2>(acc, T.fr, wave, kWv, wp, wp16, act, LD, W / 2);
-                else if (is_theta) mma_any<1, PREC, 2>(acc, T.fa, 0, kWv, wp, wp16, hs, HLD);
+                if (is_rgb)        mma_any<1, PREC, 2>(acc, kload(T.fr), wave, kWv, wp, wp16, act, LD, W / 2);
+                else if (is_theta) mma_any<1, PREC, 2>(acc, kload(T.fa), 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
                 const int colb = is_rgb ? wave * 32 : kThetaRgb;
                 const int lo = lane_id_opaque();
@@ -407,6 +436,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             CFN_MARK();                              // theta done
             // ---- 8. flows + composite: lane = sample (row), waves stride over the K latent samples
             {
+                CFN_PHASE_ARGS;
                 const int row = lane_id_opaque();
                 const bool valid = row < rows_valid;
                 float th[84];
@@ -482,6 +512,8 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             CFN_MARK();                              // flows + composite done
         }  // chunks
 
+        {   // ---- 9. the ray's outputs
+        CFN_PHASE_ARGS;
         if (MODE == 0 && tid < K) {
             float* cp = comp + tid * 8;
             const int k = tid;
@@ -520,6 +552,7 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
                 }
             }
         }
+        }
         __syncthreads();
     }  // units
 
@@ -531,7 +564,9 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
         g_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // XCC_ID
     }
 #endif
-    if (TRAIN && A.ent_partials != nullptr) {
+    if (TRAIN) {
+      CFN_PHASE_ARGS;
+      if (A.ent_partials != nullptr) {
         const float sr = wave_sum(ent_r_sum), sa = wave_sum(ent_a_sum);
         if (lane == 0) { red[wave * 2] = sr; red[wave * 2 + 1] = sa; }
         __syncthreads();
@@ -544,7 +579,12 @@ void fused_fwd_kernel(const FwdArgs A, const NetTab T) {
             A.ent_partials[blockIdx.x * 2 + 0] = e0;
             A.ent_partials[blockIdx.x * 2 + 1] = e1;
         }
+      }
     }
+#undef CFN_PHASE_ARGS
+#undef CFN_PHASE_LOCALS
+#undef CFN_KARGS
+#undef CFN_KEEP
 }
 
 // loss_entropy = mean(base_a) - mean(ld_a) + mean(base_rgb) - mean(ld_rgb)      (MOD:268,283,286)

@@ -68,9 +68,12 @@ class Trainer:
     identical seeding; step 0 uses one broadcast.  An explicit ``eps=`` argument overrides this (tests, benchmarks)."""
 
     def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False,
-                 overlap_comm=False):
+                 overlap_comm=False, time_comm=False):
         self.force_allreduce = bool(force_allreduce)
         self.overlap_comm = bool(overlap_comm)
+        # time_comm: two events on the compute stream around every gradient exchange - what the exchange EXPOSES on that stream
+        # (an exchange that ran entirely under compute would read ~0); read back with comm_stats()
+        self._comm_ev = [] if time_comm else None
         self.net: NeRF_Flows = _unwrap(net)
         dev = self.net.flat.device
         self.lrate, self.lrate_decay, self.beta1 = float(lrate), int(lrate_decay), float(beta1)
@@ -137,6 +140,33 @@ class Trainer:
         main.wait_stream(self._comm)
         self.gbuf.index_copy_(0, early, e_buf)
         e_buf.record_stream(main)
+
+    def _timed_exchange(self, fn):
+        if self._comm_ev is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self._comm_ev.append((e0, e1))
+        if len(self._comm_ev) > 4096:
+            del self._comm_ev[:2048]
+
+    def comm_stats(self, last_n=None):
+        """Exposed time of the gradient exchange over the last ``last_n`` steps (device-synchronising), its payload and what
+        torch.distributed reports about the group - the self-diagnosis block of a multi-GPU bench line."""
+        import torch.distributed as dist
+        out = {"payload_bytes": int(self.gbuf.numel() * 4), "form": "two buckets (overlap_comm)" if self.overlap_comm else "one all-reduce",
+               "backend": None, "world_size_reported": None}
+        if dist.is_available() and dist.is_initialized():
+            out["backend"] = dist.get_backend(self.group)
+            out["world_size_reported"] = dist.get_world_size(self.group)
+        ev = (self._comm_ev or [])[-(last_n or 0):]
+        if ev:
+            ev[-1][1].synchronize()
+            ms = [a.elapsed_time(b) for a, b in ev]
+            out.update(exposed_ms_mean=sum(ms) / len(ms), exposed_ms_max=max(ms), exposed_ms_min=min(ms), steps=len(ms))
+        return out
 
     def _step_eps(self):
         """Latents of the coming step, identical on every rank."""
@@ -226,7 +256,7 @@ class Trainer:
         self.forward_backward(H, W, focal, rays, target, **kw)
         if dist_on:
             self._queue_next_eps()
-            self._exchange()
+            self._timed_exchange(self._exchange)
             self._take_next_eps()
         lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
         self.t += 1
@@ -235,6 +265,7 @@ class Trainer:
                                          L.ptr(self.exp_avg_sq), self.t, C.c_float(lr), C.c_float(1.0), L.stream()),
                 "cfnerf_adam_step")
         net.mark_packed()
+        net.params_serial += 1
         return self.scalars
 
     # ---- EXTENSION (not in the reference): coarse + fine sampling through the single network -----
@@ -307,7 +338,7 @@ class Trainer:
         self.forward_backward_hierarchical(H, W, focal, rays, target, **kw)
         if dist_on:
             self._queue_next_eps()
-            allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce)
+            self._timed_exchange(lambda: allreduce_sum_(self.gbuf, self.world, self.group, self.force_allreduce))
             self._take_next_eps()
         lr = lr_at(self.lrate, self.lrate_decay, self.start, self.t)
         self.t += 1
@@ -316,6 +347,7 @@ class Trainer:
                                          L.ptr(self.exp_avg_sq), self.t, C.c_float(lr), C.c_float(1.0), L.stream()),
                 "cfnerf_adam_step")
         net.mark_packed()
+        net.params_serial += 1
         return self.scalars
 
     @property

@@ -32,6 +32,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: its dynamic symbol table holds the entry points declared in THIS header (plus
+ * the test hooks of tests/cfnerf_debug.h, which are not part of the ABI) and nothing else - no C++ symbol, no helper.
+ * tests/test_abi_cpu.py compares `nm -D --defined-only` of the library with the two headers. */
+#if defined(__GNUC__) || defined(__clang__)
+#define CFNERF_API __attribute__((visibility("default")))
+#else
+#define CFNERF_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -68,8 +77,8 @@ enum {
                                            STASH forward replaces it and bumps cfnerf_model_stash_generation */
 };
 
-int         cfnerf_version(void);
-const char* cfnerf_last_error(void);
+CFNERF_API int         cfnerf_version(void);
+CFNERF_API const char* cfnerf_last_error(void);
 
 /* ---- parameters ------------------------------------------------------------------------------
  * Parameters live in ONE flat fp32 device buffer owned by the caller, laid out in the order of
@@ -77,42 +86,42 @@ const char* cfnerf_last_error(void);
  * row-major as nn.Linear stores it ([out, in]).  cfnerf_param_count / cfnerf_param_offset describe
  * that layout so the host side can map state_dict keys to slices of the buffer.  The same layout
  * is used for gradients and Adam moments, so the multi-GPU exchange is a single all-reduce.      */
-int64_t cfnerf_param_count(const cfnerf_cfg* cfg);
+CFNERF_API int64_t cfnerf_param_count(const cfnerf_cfg* cfg);
 /* offset (in floats) and element count of a state_dict key such as "pts_linears.5.weight"; -1 if unknown */
-int64_t cfnerf_param_offset(const cfnerf_cfg* cfg, const char* key, int64_t* numel);
+CFNERF_API int64_t cfnerf_param_offset(const cfnerf_cfg* cfg, const char* key, int64_t* numel);
 /* i-th key of the layout (0 <= i < number of tensors), NULL past the end */
-const char* cfnerf_param_key(const cfnerf_cfg* cfg, int index);
+CFNERF_API const char* cfnerf_param_key(const cfnerf_cfg* cfg, int index);
 
 /* replaces: create_nerf()'s NeRF_Flows(args) construction, RUN:317-331 (device side only) */
-int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out);
-int cfnerf_model_destroy(cfnerf_model* m);
+CFNERF_API int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out);
+CFNERF_API int cfnerf_model_destroy(cfnerf_model* m);
 /* (Re)pack the flat parameter buffer into the MFMA-fragment-ordered copies the kernels stream.
  * Call after loading a checkpoint and after every optimiser step.  replaces: the implicit
  * parameter broadcast of nn.DataParallel, RUN:330 */
-int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s);
+CFNERF_API int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_stream s);
 
 /* ---- ray set-up ------------------------------------------------------------------------------
  * replaces: the ray preparation inside render(), RUN:129-158, with get_rays (HLP:288-297) and
  * ndc_rays (HLP:360-377).  Either `rays_o`/`rays_d` ([N,3] each) are given, or (c2w_host != NULL)
  * rays are generated for the N pixels pixel0 .. pixel0+N-1 (row-major) of the H x W image, so ranks can
  * tile an image by rows.  Output `rays` is the [N,11] pack o3,d3,near,far,viewdir3 of RUN:152-158. */
-int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] row-major or NULL*/,
+CFNERF_API int cfnerf_rays_setup(int H, int W, float focal, const float* c2w_host /*[3,4] row-major or NULL*/,
                       const float* rays_o, const float* rays_d, int64_t N, int64_t pixel0,
                       int ndc, float near_, float far_, float* rays /*[N,11]*/, cfnerf_stream s);
 
 /* replaces: ndc_rays(H, W, focal, near, rays_o, rays_d) as a standalone call, HLP:360-377 (render() itself goes through
  * cfnerf_rays_setup, which applies it with near = 1 like RUN:149): rays_o, rays_d [N,3] -> out_o, out_d [N,3] in NDC.
  * (get_rays, HLP:288-297, as a standalone call is cfnerf_rays_setup with c2w_host and ndc = 0: columns 0..5 of its output.)   */
-int cfnerf_ndc_rays(int H, int W, float focal, float near_, const float* rays_o, const float* rays_d, int64_t N,
+CFNERF_API int cfnerf_ndc_rays(int H, int W, float focal, float near_, const float* rays_o, const float* rays_d, int64_t N,
                     float* out_o, float* out_d, cfnerf_stream s);
 
 /* replaces: Embedder.embed / get_embedder(multires) as a standalone call, HLP:21-69:
  * x [P,3] -> out [P, 3 + 6*multires] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]        */
-int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s);
+CFNERF_API int cfnerf_embed(const float* x, int64_t P, int multires, float* out, cfnerf_stream s);
 
 /* replaces: the sampling lines of render_rays as a standalone call, RUN:510-534 (used by the unfused query path):
  * rays [N,11], t_vals [S], t_rand [N,S] or NULL, LINDISP flag -> z_vals [N,S], pts [N,S,3]                      */
-int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S,
+CFNERF_API int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S,
                          float* z_vals, float* pts, cfnerf_stream s);
 
 /* ---- fused forward ---------------------------------------------------------------------------
@@ -128,7 +137,7 @@ int cfnerf_sample_points(const float* rays, const float* t_vals, const float* t_
  *   kstats_opt [N,8]  fused reductions over the K latent samples, what the evaluation loop derives from the
  *                     per-K maps at RUN:1122-1131: mean_K rgb (3) | np.std_K(rgb) * n/(n-1) (3) | mean_K disp | mean_K depth
  *   entropy_out [1]   loss_entropy of MOD:286 (TRAIN only, may be NULL otherwise)                */
-int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand,
+CFNERF_API int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, const float* t_rand,
                       const float* z_vals_opt, const float* eps, int64_t N, int S, int K, int flags,
                       float* rgb_map, float* disp_map, float* depth_map,
                       float* raw_opt, float* weights_opt, float* pts_opt, float* kstats_opt, float* entropy_out,
@@ -139,7 +148,7 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
  * img2mse(rgb_mean, target) (RUN:1028, HLP:15), all reduced INSIDE the fused forward: only 32 (+12) bytes per pixel leave
  * the chip instead of 20*K.  Eval branch (fixed eps, no jitter).  kstats [N,8] as in cfnerf_render_fwd; gt_opt [N,3] and
  * sqerr_opt [N,3] = (K-mean rgb - gt)^2 go together or are both NULL.                                                  */
-int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, const float* eps, int64_t N, int S, int K,
+CFNERF_API int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, const float* eps, int64_t N, int S, int K,
                        int flags, const float* gt_opt, float* kstats, float* sqerr_opt, cfnerf_stream s);
 
 /* EXTENSION (not in the reference, whose N_importance / network_fine are dead parameters, RUN:467-468; the
@@ -147,18 +156,18 @@ int cfnerf_render_eval(cfnerf_model* m, const float* rays, const float* t_vals, 
  * resampling of N_importance depths per ray from the K-mean of the coarse weights, merged and sorted with the
  * coarse depths.  The coarse depths are recomputed from (rays, t_vals, t_rand, LINDISP flag) exactly as
  * cfnerf_render_fwd samples them.  weights [N,S,K], u [N,N_importance] in [0,1] -> z_out [N,S+N_importance].    */
-int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* weights,
+CFNERF_API int cfnerf_sample_pdf(const float* rays, const float* t_vals, const float* t_rand, int flags, const float* weights,
                       const float* u, int64_t N, int S, int K, int N_importance, float* z_out, cfnerf_stream s);
 
 /* replaces: NeRF_Flows.forward(x, is_val, is_test) MOD:188-291 on pre-embedded inputs x [P,90]
  * (what batchify()/run_network hand to the model, RUN:47-64,82).  raw [P,K,4].  With CFNERF_F_STASH (implies TRAIN) the
  * activations are kept for cfnerf_network_bwd (the model's ONE stash, bound as one "ray" of P samples: size the workspace
  * with cfnerf_workspace_bytes(cfg, 1, P, K)).                                                     */
-int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags,
+CFNERF_API int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags,
                        float* raw, float* entropy_out, cfnerf_stream s);
 
 /* replaces: raw2outputs() RUN:411-454 as a standalone call.  raw [N,S,K,4], z_vals [N,S], rays_d [N,3] */
-int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d,
+CFNERF_API int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d,
                          int64_t N, int S, int K, int white_bkgd,
                          float* rgb_map, float* disp_map, float* depth_map, float* weights_opt,
                          cfnerf_stream s);
@@ -169,29 +178,29 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
  * scalars_out[4] = {loss, loss_nll, mse, psnr}.  `n_total` is the GLOBAL ray count the means are
  * taken over (N for one GPU, N * world_size when rays are sharded).  scalars_out must be 8-byte aligned (its
  * 16 bytes double as the two 64-bit fixed-point accumulators of the multi-workgroup reduction).     */
-int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K,
+CFNERF_API int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* entropy, int64_t N, int K,
                         float beta1, int64_t n_total, float* d_rgb_map, float* scalars_out, cfnerf_stream s);
 
 /* ---- train-step workspace (ownership contract of SURVEY 8b) -------------------------------------
  * Bytes of device memory a CFNERF_F_STASH forward + cfnerf_render_bwd of an (N rays, S samples, K latents) batch
  * need: the activations autograd would have kept for loss.backward() (RUN:1066), the pre-activation gradients
  * and the split-K weight-gradient partials.  -1 on a bad argument.                                               */
-int64_t cfnerf_workspace_bytes(const cfnerf_cfg* cfg, int64_t N, int S, int K);
+CFNERF_API int64_t cfnerf_workspace_bytes(const cfnerf_cfg* cfg, int64_t N, int S, int K);
 /* Hand the model a caller-owned block (256-byte aligned, e.g. a torch uint8 tensor) to use as that workspace.  The
  * library then never allocates on the train path: a batch that does not fit is refused with CFNERF_E_NOMEM.  The
  * block must stay alive until the next cfnerf_model_set_workspace / cfnerf_model_destroy.  (NULL, 0) returns to
  * the default, a model-owned block grown on demand.  Any stashed forward is dropped.                            */
-int cfnerf_model_set_workspace(cfnerf_model* m, void* workspace, size_t bytes);
+CFNERF_API int cfnerf_model_set_workspace(cfnerf_model* m, void* workspace, size_t bytes);
 /* Identity of the forward the model's ONE stash currently holds: every CFNERF_F_STASH forward increments it.
  * 0 = no stashed forward.  Read it right after the forward and pass it to cfnerf_render_bwd.                    */
-uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
+CFNERF_API uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
 
 /* replaces: loss.backward() (RUN:1066) through raw2outputs, the flows and the MLP for the batch
  * of the cfnerf_render_fwd(... CFNERF_F_STASH ...) whose generation is `stash_generation`; if a later STASH forward
  * has replaced that stash the call fails (CFNERF_E_INVALID) instead of differentiating the wrong batch.
  * d_depth_map may be NULL.  d_entropy points to ONE device float, d(loss)/d(loss_entropy) (e.g. beta1); NULL
  * means 0.  grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.             */
-int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+CFNERF_API int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
                       const float* d_entropy, float* grad_flat, cfnerf_stream s);
 
 /* ---- the UNFUSED seam, differentiable like the reference's ---------------------------------------------------------
@@ -203,12 +212,12 @@ int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d
  * is `stash_generation`.  d_raw [P,K,4] = d loss / d raw (NULL = zeros), d_entropy = ONE device float, d loss /
  * d loss_entropy (NULL = 0).  grad_flat [param_count] is OVERWRITTEN.  Gradients with respect to the inputs x are not
  * produced (the reference's sample points are not parameters).                                                         */
-int cfnerf_network_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_raw, const float* d_entropy,
+CFNERF_API int cfnerf_network_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_raw, const float* d_entropy,
                        float* grad_flat, cfnerf_stream s);
 /* replaces: loss.backward() through raw2outputs(raw, z_vals, rays_d) RUN:411-454, stateless: the forward is recomputed from
  * raw [N,S,K,4], z_vals [N,S], rays_d [N,3].  d_rgb_map [N,3,K]; d_disp_map [N,K], d_depth_map [N,K], d_weights [N,S,K] may
  * be NULL (= zeros).  Writes d_raw [N,S,K,4] = d loss / d raw.  S <= 4096.                                               */
-int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K, int white_bkgd,
+CFNERF_API int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K, int white_bkgd,
                          const float* d_rgb_map, const float* d_disp_map, const float* d_depth_map, const float* d_weights,
                          float* d_raw, cfnerf_stream s);
 
@@ -219,13 +228,13 @@ int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* ray
  * reports those flat ranges (they depend on the configuration only; available after the first cfnerf_render_bwd);
  * cfnerf_stream_wait_grad_early makes `waiter` (e.g. the communication stream) wait for the event recorded at
  * that point of the LAST cfnerf_render_bwd, so the all-reduce of those ranges runs while the rest still computes. */
-int cfnerf_grad_early_ranges(cfnerf_model* m, int64_t* offsets, int64_t* counts, int max_ranges);
-int cfnerf_stream_wait_grad_early(cfnerf_model* m, cfnerf_stream waiter);
+CFNERF_API int cfnerf_grad_early_ranges(cfnerf_model* m, int64_t* offsets, int64_t* counts, int max_ranges);
+CFNERF_API int cfnerf_stream_wait_grad_early(cfnerf_model* m, cfnerf_stream waiter);
 
 /* replaces: torch.optim.Adam.step() RUN:339,1067 on the flat buffers (betas .9/.999, eps 1e-8),
  * followed by the re-pack of cfnerf_model_set_params.  step is 1-based.  grad_scale multiplies
  * the gradient first (1/world_size after a sum all-reduce).                                      */
-int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat, float* exp_avg,
+CFNERF_API int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat, float* exp_avg,
                      float* exp_avg_sq, int64_t step, float lr, float grad_scale, cfnerf_stream s);
 
 /* OPT-IN arithmetic mode of the fused forward's dense layers.  0 (default): exact-fp32 MFMA
@@ -233,7 +242,7 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
  * as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo*lo term is ~2^-18
  * relative); it is held to the SAME parity tolerances by tests/test_hip_bf16x3.py.  Applies to the fused forward,
  * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).                */
-int cfnerf_model_set_precision(cfnerf_model* m, int mode);
+CFNERF_API int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 
 /* Arithmetic of the flow phase of the fused kernels (the K conditional Sylvester flows, MOD:401-413 / FLW:225-268, the activations
  * and the composite, RUN:424-449, of every (point, latent sample)).  1: libm throughout (correctly rounded tanhf / logf / expf /
@@ -241,19 +250,19 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode);
  * (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each; tanh = 1 - 2 / (1 + e^2x)) - ~250 instructions; held to the same parity bounds
  * by the tests.  0 (default): 1 below 16 latent samples (the reference's plumbing and headline configurations stay on libm bit
  * for bit), 2 from 16 on, where the flow phase grows from 5 % (K = 16) to 20 % (K = 64, the reference's default) of the launch.   */
-int cfnerf_model_set_flow_math(cfnerf_model* m, int mode);
+CFNERF_API int cfnerf_model_set_flow_math(cfnerf_model* m, int mode);
 
 /* bytes currently held by the model: packed weights + the bound workspace, whoever owns it (diagnostics) */
-int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
+CFNERF_API int64_t cfnerf_model_workspace_bytes(const cfnerf_model* m);
 
 /* Measurement helpers for bench.py: kernel durations from HIP events recorded on the launch stream.
  *   mode 0: off (default).  mode 1: every stage of a step (ten events per train step: costs ~1 % of it).
  *   mode 2: the fused forward launch only (two events per step) - what the timed region of bench.py runs with.
  * cfnerf_timing_fwd_mean_ms: mean duration (ms) of the last min(n, 64) timed fused-forward launches since the mode was set.
  * cfnerf_timing_last_ms: last launch of a stage (stages 1..4 need mode 1).  Both return < 0 when nothing was timed.        */
-int   cfnerf_timing_enable(cfnerf_model* m, int mode);
-float cfnerf_timing_fwd_mean_ms(cfnerf_model* m, int n);
-float cfnerf_timing_last_ms(cfnerf_model* m, int which /*0=fwd 1=bwd_tail 2=bwd_data 3=bwd_dw 4=adam*/);
+CFNERF_API int   cfnerf_timing_enable(cfnerf_model* m, int mode);
+CFNERF_API float cfnerf_timing_fwd_mean_ms(cfnerf_model* m, int n);
+CFNERF_API float cfnerf_timing_last_ms(cfnerf_model* m, int which /*0=fwd 1=bwd_tail 2=bwd_data 3=bwd_dw 4=adam*/);
 
 #ifdef __cplusplus
 }

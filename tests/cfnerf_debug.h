@@ -1,0 +1,41 @@
+/*
+ * cfnerf_debug.h - TEST HOOKS exported by libcfnerf_hip.so next to the ABI of include/cfnerf.h.
+ *
+ * Not part of the drop-in boundary: nothing in cf-nerf_amd/ (the product's host side) calls them; they let tests/ read
+ * internal state that the ABI deliberately hides - the packed operand layout, the weight-gradient plan, the activation
+ * stash of the last CFNERF_F_STASH forward.  tests/test_abi_cpu.py holds the library's dynamic symbol table to exactly
+ * the union of include/cfnerf.h and this header.
+ */
+#ifndef CFNERF_DEBUG_H
+#define CFNERF_DEBUG_H
+
+#include "cfnerf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* floats of the packed (MFMA-fragment-ordered) operand buffer of a configuration; < 0: rejected configuration */
+CFNERF_API int64_t cfnerf_debug_packed_floats(const cfnerf_cfg* cfg);
+/* pack flat parameters on the HOST with the index map the device pack kernel uses (cfnerf_layout.h: pack_map) */
+CFNERF_API int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float* packed_host);
+/* operand-table entry by name ("trunk", "skipseg", "ha", ... "bt_trunk"): out[4] = {w_off, b_off, kc, nt} */
+CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out);
+/* copy a buffer of the last STASH forward / its backward ("h", "g_h", "feat", "v", "theta", "enc", "at", ...) into dst (device);
+ * returns the float count, -count if max_floats is too small, -1 if there is no such buffer */
+CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s);
+/* the weight-gradient tiles of a configuration at P points: 12 int32 per tile + 4 destination segments each */
+CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles);
+/* the blocks of that plan for a point count and CU count: 5 int64 per block {kind, tile, split, pb, pe}, per tile its split count,
+ * per parameter tensor the slot count of the reduction */
+CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
+                                      int32_t* seg_nsplit, int max_segs);
+#ifdef CFN_TIMESTAMP
+/* (timeline builds, -DCFN_TIMESTAMP only) the s_memrealtime marks of the fused forward, tests/tools/wg_timeline.py */
+CFNERF_API int cfnerf_debug_read_dbg(unsigned long long* host, int n);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -25,6 +25,9 @@ if os.path.exists("/dev/kfd"):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("CFNERF_GRAD_STATS_ONLY"):
+        raise pytest.UsageError("CFNERF_GRAD_STATS_ONLY is set: rounds 2-3 used it to switch the gradient assertions off for surveys; it is no "
+                                "longer honoured and must not reach a test run (CFNERF_GRAD_STATS=<path> alone logs every comparison AND judges it)")
     # never test a stale library: rebuild in-tree when a source is newer than libcfnerf_hip.so (no-op otherwise)
     import importlib.util
     import shutil

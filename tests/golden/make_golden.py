@@ -124,6 +124,18 @@ def build_reference_model(R, cfg, seed, tmpdir, **over):
     return args, kw_train, kw_test, model, p, optimizer
 
 
+def reference_kde_nll(rgbs, target, nk, eps=1e-05):
+    """The reference's KDE negative log-likelihood, lines RUN:1032-1042 executed on reference tensors (``train()`` cannot be imported
+    as a function, so its loss lines are restated HERE, once, operation for operation - the fixtures pin the result bit for bit):
+    bandwidth H = unbiased std_K * n/(n-1) * (0.8/n)^(-1/7) + eps (detached), p = mean_K N(target; c_k, H^2) + eps, nll = -mean log p."""
+    import math
+    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
+    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
+    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
+    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
+    return -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+
+
 def fern_rays(rng, n, H=378, W=504, focal=407.5658):
     """Fern-shaped synthetic rays: identity-ish pose, random pixels."""
     c2w = np.eye(4, dtype=np.float32)[:3]
@@ -228,11 +240,7 @@ def psnr_curve_fixture(R, tmp):
         img_loss = torch.mean((rgb_mean - target) ** 2)
         psnr = -10. * torch.log(img_loss) / torch.log(torch.Tensor([10.]))
         nk, eps = K, 1e-05                                                                  # RUN:1030-1050
-        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-        H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
-        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-        loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+        loss_nll = reference_kde_nll(rgbs, target, nk)
         loss_entropy = extras["loss_entropy"].mean()
         loss = loss_nll + c["beta1"] * loss_entropy
         optimizer.zero_grad()                                                               # RUN:1065-1067
@@ -359,15 +367,8 @@ def main():
         mse = HLP.img2mse(rgb_mean, target)
         psnr = HLP.mse2psnr(mse)
         import math
-        eps = 1e-05
         nk = K
-        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-        H_sqrt = rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps
-        H_sqrt = H_sqrt[..., None]
-        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-        r_P_C_mean = (r_P_C_1 * r_P_C_2).mean(-1) + eps
-        loss_nll = -torch.log(r_P_C_mean).mean()
+        loss_nll = reference_kde_nll(rgbs, target, nk)
         loss_entropy = extras["loss_entropy"].mean()
         loss = loss_nll + beta1 * loss_entropy
         optimizer.zero_grad()
@@ -550,11 +551,7 @@ def main():
             rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False,
                                                  **kw_train)
         nk, eps = 4, 1e-05                                                                  # RUN:1026-1050
-        rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-        H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
-        r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-        r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-        loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+        loss_nll = reference_kde_nll(rgbs, target, nk)
         loss = loss_nll + beta1 * extras["loss_entropy"].mean()
         optimizer.zero_grad()                                                               # RUN:1065-1067
         loss.backward()
@@ -593,11 +590,7 @@ def main():
     with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
         rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
     nk, eps, beta1 = 16, 1e-05, 0.01
-    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
-    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss_nll = reference_kde_nll(rgbs, target, nk)
     loss = loss_nll + beta1 * extras["loss_entropy"].mean()
     optimizer.zero_grad()
     loss.backward()
@@ -625,11 +618,7 @@ def main():
     with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
         rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
     nk, eps, beta1 = 3, 1e-05, 0.02
-    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
-    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss_nll = reference_kde_nll(rgbs, target, nk)
     loss = loss_nll + beta1 * extras["loss_entropy"].mean()
     optimizer.zero_grad()
     loss.backward()
@@ -667,11 +656,7 @@ def main():
     with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
         rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
     nk, eps, beta1 = 100, 1e-05, 0.01
-    rgb_std = torch.std(rgbs, -1) * nk / (nk - 1)
-    H_sqrt = (rgb_std.detach() * torch.pow(0.8 / nk, torch.tensor(-1 / 7)) + eps)[..., None]
-    r_P_C_1 = torch.exp(-((rgbs - target[..., None]) ** 2) / (2 * H_sqrt * H_sqrt))
-    r_P_C_2 = torch.pow(torch.tensor(2 * math.pi), -1.5) / H_sqrt
-    loss_nll = -torch.log((r_P_C_1 * r_P_C_2).mean(-1) + eps).mean()
+    loss_nll = reference_kde_nll(rgbs, target, nk)
     loss = loss_nll + beta1 * extras["loss_entropy"].mean()
     optimizer.zero_grad()
     loss.backward()

@@ -15,15 +15,37 @@ from oracle import cfnerf_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "cfnerf.h")).read()
+def _declared(path):
+    hdr = open(path).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(cfnerf_[a-z_0-9]+)\s*\(", hdr))
+    hdr = re.sub(r"#ifdef CFN_TIMESTAMP.*?#endif", "", hdr, flags=re.S)          # timeline builds only
+    return set(re.findall(r"\bCFNERF_API\b[^;(]*?\b(cfnerf_[a-z_0-9]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared(os.path.join(ROOT, "include", "cfnerf.h"))
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     lib = C.CDLL(L.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
     assert L.lib().cfnerf_version() >= 100
+
+
+def test_dynamic_symbol_table_is_exactly_the_two_headers():
+    """The library is built with -fvisibility=hidden: `nm -D --defined-only` must list the entry points of include/cfnerf.h, the test
+    hooks of tests/cfnerf_debug.h and NOTHING else - no C++ symbol, no internal helper (round 3 exported 226 mangled names and seven
+    undeclared C ones)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    exported -= {"_init", "_fini", "__bss_start", "_edata", "_end"}              # linker-provided
+    abi = _declared(os.path.join(ROOT, "include", "cfnerf.h"))
+    hooks = _declared(os.path.join(ROOT, "tests", "cfnerf_debug.h"))
+    assert abi and hooks and not (abi & hooks)
+    assert all(h.startswith("cfnerf_debug_") for h in hooks), hooks
+    assert exported == abi | hooks, {"undeclared": sorted(exported - abi - hooks)[:10], "missing": sorted((abi | hooks) - exported)}
 
 
 @pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64), (192, 32, 64), (320, 64, 32), (448, 32, 32), (256, 96, 128), (64, 128, 96)])

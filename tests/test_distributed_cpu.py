@@ -132,3 +132,86 @@ def test_row_tiled_evaluation_gathers_the_full_image_on_rank_0():
     np.testing.assert_array_equal(got["disp_mean"], np.arange(H * W, dtype=np.float32).reshape(H, W))
     np.testing.assert_array_equal(got["depth_mean"], -np.arange(H * W, dtype=np.float32).reshape(H, W))
     assert got["rgb_unc"].shape == (H, W, 3) and abs(got["mse"] - 0.25) < 1e-7
+
+
+# ---- sharded ray pool (replaces RUN:860-884, 942-951 + the DataParallel split of RUN:330 across processes) ----------
+_POOL_M, _POOL_NRAND, _POOL_STEPS = 1003, 64, 20          # 1003 rays, windows of 2 x 64: the epoch's last window is short AND odd
+
+
+def _pool_table():
+    return torch.arange(_POOL_M * 9, dtype=torch.float32).reshape(_POOL_M, 3, 3)
+
+
+def _pool_worker(rank, world, port, q, sync):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cfnerf_amd.data import RayPool
+    torch.manual_seed(100 + rank)                         # DIFFERENT global seeds per rank: the permutation must still be ONE
+    if sync == "broadcast":                               # rank 0's own generator draws it, the others receive it
+        pool = RayPool.from_rays_rgb(_pool_table(), _POOL_NRAND, rank=rank, world=world, sync="broadcast",
+                                     generator=torch.Generator().manual_seed(77 + rank))
+    else:
+        pool = RayPool.from_rays_rgb(_pool_table(), _POOL_NRAND, rank=rank, world=world, sync="seed", seed=77)
+    assert pool.sync == sync and pool.global_batch == world * _POOL_NRAND
+    out = []
+    for _ in range(_POOL_STEPS):
+        rays, target = pool.next_batch()
+        out.append((rays.clone().numpy(), target.clone().numpy(), pool.epoch, pool.i_batch))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_pool(sync):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pool_worker, args=(r, world, port, q, sync)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    return got
+
+
+def test_sharded_ray_pool_union_of_shards_is_the_single_process_batch():
+    """Two ranks over gloo, rank 0's permutation broadcast once per epoch: at every step - across two epoch boundaries with a short,
+    odd last window - the concatenation of the shards is the batch ONE process with N_rand_global = 2 x 64 draws from the same
+    permutation, the ranks re-shuffle at the same step, and no ray is delivered twice inside an epoch."""
+    from cfnerf_amd.data import RayPool
+    got = _run_pool("broadcast")
+    # the one-process pool replays rank 0's draws: same generator seed
+    one = RayPool.from_rays_rgb(_pool_table(), 2 * _POOL_NRAND, generator=torch.Generator().manual_seed(77))
+    seen, epochs = set(), []
+    for step in range(_POOL_STEPS):
+        e_before = one.epoch
+        rays1, tgt1 = one.next_batch()
+        (r0, t0, ep0, ib0), (r1, t1, ep1, ib1) = got[0][step], got[1][step]
+        assert (ep0, ib0) == (ep1, ib1) == (one.epoch, one.i_batch), step          # same epoch / cursor on every rank at every step
+        assert r0.shape == r1.shape and r0.shape[1] in (_POOL_NRAND, (_POOL_M % (2 * _POOL_NRAND)) // 2)
+        union_r, union_t = np.concatenate([r0, r1], 1), np.concatenate([t0, t1], 0)
+        n = union_r.shape[1]
+        assert n == rays1.shape[1] - (rays1.shape[1] % 2)                         # a ragged window loses at most world - 1 rays
+        np.testing.assert_array_equal(union_r, rays1.numpy()[:, :n])
+        np.testing.assert_array_equal(union_t, tgt1.numpy()[:n])
+        ids = set((union_t[:, 0] // 9).astype(int).tolist())                      # row id of the table the ray came from
+        if e_before != (epochs[-1] if epochs else 0):
+            seen = set()
+        epochs.append(e_before)
+        assert not (ids & seen), step
+        seen |= ids
+    assert one.epoch == 2                                                         # two re-shuffles were crossed
+
+
+def test_sharded_ray_pool_seed_form_needs_no_exchange():
+    from cfnerf_amd.data import RayPool
+    got = _run_pool("seed")
+    one = RayPool.from_rays_rgb(_pool_table(), 2 * _POOL_NRAND, seed=77)
+    for step in range(_POOL_STEPS):
+        rays1, tgt1 = one.next_batch()
+        union_t = np.concatenate([got[0][step][1], got[1][step][1]], 0)
+        np.testing.assert_array_equal(union_t, tgt1.numpy()[:union_t.shape[0]])

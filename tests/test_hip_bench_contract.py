@@ -120,3 +120,38 @@ def test_gpus_2_starts_its_own_ranks(argv, workload):
         assert abs(two["value"] - 2 * 1024 / (two["ms_per_step"] * 1e-3)) <= 1e-6 * two["value"]
     ratio = two["value"] / one["value"]
     assert 0.5 <= ratio <= 1.10, (ratio, one["value"], two["value"])
+
+
+def test_gpus_2_default_line_explains_itself():
+    """The N > 1 line carries the whole metric and its own diagnosis: `psnr` (sharded ray pool + Trainer on world x 1024-ray global
+    batches, with the pass/fail `vs_single_process`), `comm` (exposed exchange time from two HIP events around the all-reduce, payload,
+    the backend and world size torch.distributed reports), `rank_skew`, and `cpu_baseline` on rank 0.  Two ranks on cuda:0 over gloo."""
+    d = run_bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--psnr-steps", "60", env={"CFNERF_BENCH_SAME_GPU": "1"}, timeout=1500)
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("C2")
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["world_size_reported"] == 2 and c["steps"] == 4
+    assert c["payload_bytes"] >= 617410 * 4 and c["form"] == "one all-reduce"
+    assert 0.0 < c["exposed_ms_min"] <= c["exposed_ms_mean"] <= c["exposed_ms_max"]
+    assert c["exposed_ms_mean_min_over_ranks"] <= c["exposed_ms_mean"] <= c["exposed_ms_mean_max_over_ranks"] + 1e-9
+    assert 0.0 < c["frac_of_step"] < 1.0
+    k = d["rank_skew"]
+    assert k["ms_per_step_min"] <= k["ms_per_step_max"] and abs(k["ms_per_step_max"] - d["ms_per_step"]) <= 1e-6 * d["ms_per_step"]
+    assert k["fwd_launch_ms_min"] <= d["roofline"]["launch_ms"] <= k["fwd_launch_ms_max"] + 1e-9
+    p = d["psnr"]
+    assert p["n_gpus"] == 2 and p["global_batch"] == 2048 and p["steps"] == 60 and "world=2" in p["feeder"]
+    cv = p["held_out_psnr_db_by_step"]
+    assert cv["60"] > cv["0"] + 1.0, cv                                     # it trains across the ranks
+    v = p["vs_single_process"]
+    assert v["agree"] is True and v["abs_psnr_diff_db"] <= v["tolerance_db"] == 0.05
+    assert v["max_abs_param_diff_rel"] < 5e-2                               # (Adam sign flips of ~0 gradients move single weights)
+    assert p["vs_oracle"]["agree"] is True and p["vs_reference_run"]["agree"] is True
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0
+    assert "config4_k16" in d and "alt_precision" in d
+
+
+def test_k64_config_runs():
+    """the reference's default latent count (--K_samples 64, RUN:631) as a bench configuration"""
+    d = run_bench("--config", "K64", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline")
+    assert d["config"]["workload"].startswith("K64") and "K=64" in d["config"]["workload"] and d["value"] > 0
+    assert d["kernel_ms"]["bwd_tail"] > 0.1                                 # the tail kernel is K-proportional: ~0.34 ms at K = 64

@@ -694,3 +694,55 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)
     check_all_grads(net, grad, grads, what)
+
+
+def test_one_hot_cotangent_reaches_every_ray_at_production_batch():
+    """A SHARP per-ray check at the production batch size (N = 1024): d loss / d rgb_map is non-zero for ONE ray i, so every gradient
+    is that ray's alone - no cancellation between rays, hence no sum|c| allowance (util_hip.grad_close_tight needs one for the
+    base-Gaussian tensors of a full-batch gradient, and at N >= 1000 a reduction that dropped one ray would hide inside it).  Reference:
+    the fp64 oracle on THAT ray only (a batch of one), on the ReLU masks the HIP forward took for its 128 points.  Rays at the edges of
+    every partition the backward makes: the first / last of the batch, both sides of a 64-ray boundary, the middle, a random one.
+    Held to ONE_RAY_TOL of each tensor's largest entry: the base Gaussians (reduce_gms), every bias (reduce_bias), the heads and
+    flow heads (tail_bwd -> dw_small) and the trunk (bwd_data -> dw_big)."""
+    from util_hip import hip_relu_masks
+    ONE_RAY_TOL = 2e-5
+    cfg = O.OracleCfg(netwidth=64, K_samples=4)
+    _, kw_train, _, model, p, optimizer = build_model(cfg, 77)
+    net = model.module
+    rng = np.random.default_rng(123)
+    N, K, S = 1024, 4, 128
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32)
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    rgbs, _, _, _ = cfnerf_amd.render(H, Wd, focal, rays=rays.to(DEV), t_rand=t_rand, eps_alpha=ea, eps_rgb=er, **kw_train)
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    d = lambda t: t.double()
+    worst = {}
+    for i in (0, 63, 64, 511, N - 1, int(rng.integers(65, N - 1))):
+        Gi = torch.tensor(rng.standard_normal((3, K)), dtype=torch.float32)
+        G = torch.zeros(N, 3, K)
+        G[i] = Gi
+        optimizer.zero_grad()
+        (rgbs * G.to(DEV)).sum().backward(retain_graph=True)
+        g_hip = net.flat.grad.detach().cpu().double()
+        _, masks = hip_relu_masks(net, N * S, rows=(i * S, (i + 1) * S))
+        q = {k: d(v).clone().requires_grad_(True) for k, v in p.items()}
+        with O.relu_override(masks=masks):
+            r = O.render_rays(q, d(packed[i:i + 1]), cfg, d(ea), d(er), True, d(t_rand[i:i + 1]))
+        close(rgbs[i:i + 1], r["rgb_map"].detach(), what=f"rgb_map of ray {i}")
+        (r["rgb_map"] * d(Gi)[None]).sum().backward()
+        for key, (off, cnt) in net.layout.items():
+            ref = q[key].grad
+            got = g_hip[off:off + cnt]
+            if ref is None:
+                assert not got.any(), (i, key)
+                continue
+            ref = ref.reshape(-1)
+            scale = float(ref.abs().max())
+            assert scale > 0, (i, key)
+            err = float((got - ref).abs().max()) / scale
+            worst[key] = max(worst.get(key, 0.0), err)
+            assert torch.all((got - ref).abs() <= ONE_RAY_TOL * scale + 1e-4 * ref.abs()), \
+                f"ray {i}, {key}: max error {err:.2e} of the largest entry exceeds {ONE_RAY_TOL:.0e}"
+    print("one-hot cotangent, worst error / largest entry per tensor:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})

@@ -76,7 +76,8 @@ def fern_rays(rng, n, H=378, W=504, focal=407.5658):
 G_TIGHT = 2e-4            # of the tensor's largest entry
 
 
-def stash_copy(net, name, layer, n):
+def stash_copy(net, name, layer, n, keep=None):
+    """buffer `name` of the last STASH forward as a CPU tensor; keep = (lo, hi): only that range of its floats crosses to the host"""
     import ctypes as C
     from cfnerf_amd import _lib as L
     lib = L.lib()
@@ -86,14 +87,15 @@ def stash_copy(net, name, layer, n):
     out = torch.empty(n, device="cuda")
     r = fn(net.handle, name.encode(), layer, C.c_void_p(out.data_ptr()), n, L.stream())
     assert r == n, (name, layer, r, n)
-    return out.cpu()
+    return (out if keep is None else out[keep[0]:keep[1]]).cpu()
 
 
-def hip_relu_masks(net, P):
-    """0/1 masks of the last STASH forward: trunk<i> [P,W], views [P,W/2] (post-ReLU activation > 0)."""
+def hip_relu_masks(net, P, rows=None):
+    """0/1 masks of the last STASH forward: trunk<i> [P,W], views [P,W/2] (post-ReLU activation > 0); rows = (lo, hi): of those points only"""
     W, D = net.W, net.D
-    acts = {f"trunk{i}": stash_copy(net, "h", i, P * W).reshape(P, W) for i in range(D)}
-    acts["views"] = stash_copy(net, "v", 0, P * (W // 2)).reshape(P, W // 2)
+    lo, hi = rows if rows is not None else (0, P)
+    acts = {f"trunk{i}": stash_copy(net, "h", i, P * W, (lo * W, hi * W)).reshape(hi - lo, W) for i in range(D)}
+    acts["views"] = stash_copy(net, "v", 0, P * (W // 2), (lo * (W // 2), hi * (W // 2))).reshape(hi - lo, W // 2)
     return acts, {k: (v > 0).float() for k, v in acts.items()}
 
 
@@ -199,6 +201,7 @@ G_FLOOR, G_CAP, G_NOISE_X = 2e-5, 1e-3, 16.0
 G_ABS_EPS = 1e-7           # absolute floor of every comparison, in units of the step's largest gradient entry
 G_SUM_REL = 1e-3           # base-Gaussian gradients: allowance relative to the sum of the magnitudes of the terms they add up
 G_ALPHA_X = 2.0            # the density ("alpha") path is the ill-conditioned one (transmittance adjoint): twice the noise multiple
+G_CAP_OTHER = 2e-4         # every tensor OUTSIDE the alpha path: the calibration can only tighten the fixed bound of round 2, never loosen it
 
 
 def grad_close_tight(g, ref, what, tol=None):
@@ -218,9 +221,10 @@ def grad_close_tight(g, ref, what, tol=None):
     ref = np.asarray(ref, dtype=np.float64)
     g = g.detach().cpu().double().numpy() if torch.is_tensor(g) else np.asarray(g, dtype=np.float64)
     nx = G_NOISE_X * (G_ALPHA_X if ("alpha" in what) else 1.0)
+    cap = G_CAP if ("alpha" in what) else G_CAP_OTHER
     if tol is None:
-        tol = G_TIGHT if noise is None else min(max(nx * noise, G_FLOOR), G_CAP)
-    tol_rms = tol if noise is None else min(max(nx * noise, 1.5 * G_FLOOR), G_CAP)
+        tol = G_TIGHT if noise is None else min(max(nx * noise, G_FLOOR), cap)
+    tol_rms = tol if noise is None else min(max(nx * noise, 1.5 * G_FLOOR), cap)
     scale = max(float(np.abs(ref).max()), 1e-12)
     rms_rel = float(np.sqrt(((g - ref) ** 2).sum() / max(float((ref ** 2).sum()), 1e-300)))
     stats = os.environ.get("CFNERF_GRAD_STATS")          # development aid: log the measured error of every comparison
@@ -229,8 +233,8 @@ def grad_close_tight(g, ref, what, tol=None):
         with open(stats, "a") as f:
             f.write(json.dumps({"what": what, "rel_to_max": float(np.abs(g - ref).max() / scale), "scale": scale, "n": int(ref.size),
                                 "rms_rel": rms_rel, "noise": noise, "tol": tol}) + "\n")
-    if stats and os.environ.get("CFNERF_GRAD_STATS_ONLY") == "1":
-        return                                           # survey mode: record every comparison, judge none
+    # (there is no "record only" mode: a variable that switched the assertions off would make every gradient test pass vacuously
+    # wherever it leaked to; tests/conftest.py refuses to start with the old CFNERF_GRAD_STATS_ONLY set)
     if sum_abs is not None:                              # a cancelling sum: absolute allowance of G_SUM_REL x sum |terms| per entry
         allow = G_SUM_REL * np.asarray(sum_abs, dtype=np.float64).reshape(ref.shape)
         err = np.abs(g - ref)

@@ -5,10 +5,10 @@ set -euo pipefail
 R="$(cd "$(dirname "$0")/.." && pwd)"
 name="$1"; shift
 O="$R/cf-nerf_amd/build/var_$name"; mkdir -p "$O"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-result -Wno-unused-value"
 for f in cfnerf_fwd cfnerf_bwd cfnerf_abi; do
   hipcc $FLAGS "$@" -c "$R/cf-nerf_amd/csrc/$f.hip" -o "$O/$f.o" &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/cf-nerf_amd/libvar_$name.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_abi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -o "$R/cf-nerf_amd/libvar_$name.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_abi.o
 echo "$R/cf-nerf_amd/libvar_$name.so"
