@@ -270,7 +270,7 @@ def launch_ranks(n, argv):
         have = int(torch.cuda._device_count_amdsmi())
     except Exception:
         have = -1
-    if not same_gpu and 0 <= have < n:
+    if not same_gpu and 0 <= have < n:         # (negative = amdsmi could not tell: let the ranks find out)
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (CFNERF_BENCH_SAME_GPU=1 runs the N-rank code path on one GPU over gloo)",
               file=sys.stderr)
         return 2

@@ -516,7 +516,11 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
         float* lrow = lds_dst + rbase * ld;
         const int voff = (rbase * gld + col) * 4;
         const uint32_t mb = e.mb[j];
+#ifdef CFN_CSUM_PK        // (A/B builds, round 4) the column sum of a row pair as ONE packed fp32 add
+        f32x2 cs2; cs2[0] = 0.f; cs2[1] = 0.f;
+#else
         float csum = 0.f;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -529,8 +533,16 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, col, v0, v1);
                 slab_store(sink, voff, rr * gld * 4, v0);
                 slab_store(sink, voff, (rr + 1) * gld * 4, v1);
+#ifdef CFN_CSUM_PK
+                f32x2 v2; v2[0] = v0; v2[1] = v1;
+                cs2 += v2;
+#else
                 csum += v0; csum += v1;
+#endif
             }
+#ifdef CFN_CSUM_PK
+        float csum = cs2[0] + cs2[1];
+#endif
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }

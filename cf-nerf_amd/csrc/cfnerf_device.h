@@ -46,6 +46,15 @@ __device__ __forceinline__ V sgpr_fresh(V v) {
     asm volatile("" : "+s"(v));
     return v;
 }
+// ... and a device-memory pointer: laundered AS a global-address-space pointer, so what is reached through it stays global_load /
+// global_store (a laundered generic pointer has lost its provenance and every access through it becomes a flat_* instruction)
+template <class V>
+__device__ __forceinline__ V* sgpr_fresh(V* p) {
+    typedef V __attribute__((address_space(1)))* gptr;
+    gptr g = (gptr)p;
+    asm volatile("" : "+s"(g));
+    return (V*)g;
+}
 // by-value copy of a table entry out of the kernarg segment (scalar loads)
 template <class V>
 __device__ __forceinline__ V kload(const CFN_KCONST V& src) {
@@ -55,6 +64,16 @@ __device__ __forceinline__ V kload(const CFN_KCONST V& src) {
 }
 template <class V>
 __device__ __forceinline__ V kload(const V& src) { return src; }
+// an operand-table entry is 16 bytes: ONE s_load_dwordx4 (field by field the compiler issues a dword load + a full wait per field, at
+// each field's first use)
+typedef uint32_t u32x4_k __attribute__((ext_vector_type(4), aligned(4)));
+template <>
+__device__ __forceinline__ SubL kload<SubL>(const CFN_KCONST SubL& src) {
+    const u32x4_k v = *reinterpret_cast<const CFN_KCONST u32x4_k*>(&src);
+    SubL r;
+    __builtin_memcpy(&r, &v, sizeof(SubL));
+    return r;
+}
 
 // activation row stride (floats): +4 keeps ds_read_b128 of 16 consecutive rows conflict-free
 // (row stride = 16 B mod 256 B) and rows 16-B aligned.  >= 128 so the theta tile fits.
@@ -315,7 +334,7 @@ template <int NTW, int PRE>
 __device__ __forceinline__ void mma_seg16(f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, const __bf16* __restrict__ wp16,
                                           const float* lds_a, int lda, int col0) {
     const int lane = lane_id_opaque();
-    const int KC = s.kc16;
+    const int KC = s.kc16();
     int nvalid = 0;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) nvalid += (nt0 + j * nts < (int)s.nt) ? 1 : 0;
@@ -355,7 +374,7 @@ __device__ __forceinline__ void mma_ksplit(f32x16 (&acc)[2][1], const SubL s, in
     // with a zero trip count (their prefetches read in-range or bounds-checked addresses and feed no MFMA).
     const int ntc = (int)s.nt, nt = wave % ntc, part = wave / ntc, nparts = n_waves / ntc;
     if (PREC == PREC_BF16X3) {
-        const int KC = s.kc16, kcp = (KC + nparts - 1) / nparts, k0 = min(part * kcp, KC), cnt = min(kcp, KC - k0);
+        const int KC = s.kc16(), kcp = (KC + nparts - 1) / nparts, k0 = min(part * kcp, KC), cnt = min(kcp, KC - k0);
         const float* a_row = lds_a + (lane & 31) * lda;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp16), 0, 0x7ffffff0, 0x00020000);
         const int so[1] = {__builtin_amdgcn_readfirstlane((int)(s.w16_off * 2u + ((unsigned)nt * KC + k0) * 2048u))};
@@ -488,7 +507,17 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 if (ACT == ACT_RELU) { v0 = relu_f(v0); v1 = relu_f(v1); }
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, lcol, v0, v1);
                 if (STASH) { slab_store(sink, voff, rr * gld * 4, v0); slab_store(sink, voff, (rr + 1) * gld * 4, v1); }
+#ifdef CFN_MASK_PKADD     // (A/B builds, round 4) the two "0 - v" of a row pair as ONE packed fp32 subtract: the sign of +0 - v is set iff v > 0
+                if (WANT_BITS) {
+                    f32x2 v2; v2[0] = v0; v2[1] = v1;
+                    f32x2 z2; z2[0] = 0.f; z2[1] = 0.f;
+                    const f32x2 n2 = z2 - v2;
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(n2[0]), 31);
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(n2[1]), 31);
+                }
+#else
                 if (WANT_BITS) { bits = relu_bit_push(bits, v0); bits = relu_bit_push(bits, v1); }
+#endif
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there

@@ -223,7 +223,13 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             // hold them before a layer's first MFMA, so a fetch at the top of the layer is an exposed L2 round trip per layer):
             // layer 0's rides under the encoding, layer l+1's under layer l's MFMAs, and so on down the heads.
             float bias_n[C::NTW];
-            load_bias<C::NTW>(kload(T.trunk[0]), wave, kWv, wp, bias_n);
+            // Operand-table entries travel ONE PHASE AHEAD as well (16 bytes = one s_load_dwordx4 each, cfnerf_device.h: kload): a trunk layer
+            // runs on the entry fetched two layers earlier, prefetches the next layer's bias with the entry fetched one layer earlier, and
+            // fetches the one after - so no layer starts by waiting for the constant cache in front of its first weight loads.
+            SubL tl_cur = kload(T.trunk[0]);
+            SubL tl_nxt = kload((1 < Dn) ? T.trunk[1] : T.ft);
+            const SubL tl_skip = kload(T.skipseg);
+            load_bias<C::NTW>(tl_cur, wave, kWv, wp, bias_n);
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
             // gamma(p) is needed again at the skip layer, five layers later, when the in-place tile has long been overwritten.
@@ -272,10 +278,17 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             for (int l = 0; l < Dn; ++l) {
                 CFN_PHASE_ARGS;
                 f32x16 acc[2][C::NTW];
+                const SubL tl_nn = kload((l + 2 < Dn) ? T.trunk[l + 2] : T.ft);                 // (in flight under this layer's MFMAs)
                 acc_init(acc, bias_n);
-                load_bias<C::NTW>(kload((l + 1 < Dn) ? T.trunk[l + 1] : T.ft), wave, kWv, wp, bias_n);     // next layer's / the feature head's
+                // the accumulators take the bias fetched a layer ago (its wait also drains the previous layer's stash stores: one counter);
+                // only THEN is the next layer's bias requested - hoisted above that wait it would expose an L2 round trip per layer
+                asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][C::NTW - 1][0]) : "memory");
+                load_bias<C::NTW>(tl_nxt, wave, kWv, wp, bias_n);                               // next layer's / the feature head's
                 CFN_MARK();                          // MFMA phase of layer l starts
-                mma_any<C::NTW, PREC, 2>(acc, kload(T.trunk[l]), wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(acc, tl_cur, wave, kWv, wp, wp16, act, LD);
+                // (all four dwords of the prefetched entry stay live to here: the fp32 kernels never read w16_off, and a dead destination
+                // register of an s_load in flight gets reused at once - a write-after-write wait on the load that was meant to be hidden)
+                asm volatile("" :: "s"(tl_nn.w16_off));
                 CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == skip_l) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
@@ -299,19 +312,21 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                         encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
                     }
                     __syncthreads();
-                    mma_any<C::NTW, PREC, 2>(acc, kload(T.skipseg), wave, kWv, wp, wp16, act, LD);
+                    mma_any<C::NTW, PREC, 2>(acc, tl_skip, wave, kWv, wp, wp16, act, LD);
                 }
                 __syncthreads();
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
                 uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, kload(T.trunk[l]), wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
                 if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
                 CFN_MARK();                          // epilogue + barrier done
+                tl_cur = tl_nxt; tl_nxt = tl_nn;
             }
+            const SubL tl_ft = tl_cur;               // after the last layer: the feature head's entry
 
             // ---- 4. heads: h_alpha = A h (MOD:175), feature = F h (MOD:176).  h_alpha is only 1-2 n-tiles wide: its K is
             //         split over the 4 waves (a quarter or half each) and the partial tiles are summed through act[] once
@@ -324,7 +339,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 acc_init(accF, bias_n); acc_zero(accA);
                 load_bias<C::NTV>(kload(T.vf), wave, kWv, wp, bias_v);
                 mma_ksplit<PREC, 2>(accA, kload(T.ha), wave, kWv, wp, wp16, act, LD);
-                mma_any<C::NTW, PREC, 2>(accF, kload(T.ft), wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
                 {
                     const int lo = lane_id_opaque();
@@ -349,7 +364,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
                 __syncthreads();
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, kload(T.ft), wave, kWv, wp, act, LD, 0,
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, tl_ft, wave, kWv, wp, act, LD, 0,
                                               A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
                 if (kRows && A.st_feat != nullptr) stash_rows<W, kThr>(act, LD, A.st_feat + p0 * W, rows_valid);

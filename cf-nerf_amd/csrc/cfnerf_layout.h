@@ -97,6 +97,11 @@ inline ParamLayout build_layout(const cfnerf_cfg& c) {
     return L;
 }
 
+#if defined(__HIPCC__)
+#define CFN_HD_EARLY __host__ __device__
+#else
+#define CFN_HD_EARLY
+#endif
 // One packed GEMM operand: B fragments of an [N_out x K_red] matrix for v_mfma_f32_32x32x2_f32.
 //   packed[((nt * kc_count + kc) * 64 + lane) * 4 + c] = M[nt*32 + (lane & 31)][kc*8 + 4*(lane >> 5) + c]
 // (zero outside the valid range).  A float4 per lane feeds 4 MFMAs; the A operand uses the same
@@ -110,9 +115,10 @@ struct SubL {
     //   packed16[w16_off + (((nt*kc16 + c)*2 + plane)*64 + lane)*8 + e] = bf16 part `plane` (0 hi, 1 lo) of
     //   M[nt*32 + (lane&31)][c*16 + 8*(lane>>5) + e]
     uint32_t w16_off;    // in bf16 elements
-    uint16_t kc16;       // k chunks of 16
-    uint16_t pad_;
+    // k chunks of 16 of that copy: the reduction axis is padded to 16 there, 8 here
+    CFN_HD_EARLY int kc16() const { return (kc + 1) >> 1; }
 };
+static_assert(sizeof(SubL) == 16, "one table entry = ONE 16-byte scalar load from the kernarg segment (kload)");
 
 // theta (flow-parameter) column map inside a tile row: rgb heads [0,96), alpha heads [96,128).  The kernels are built for
 // kFlowsMax = 4 flow steps and address a parameter of step f as (block) * 4 + f:
@@ -214,8 +220,7 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
         SubL s;
         s.nt = (uint16_t)(pad_to(n_out, 32) / 32);
         s.kc = (uint16_t)(pad_to(k_red, 8) / 8);
-        s.kc16 = (uint16_t)(pad_to(k_red, 16) / 16); s.pad_ = 0;
-        s.w16_off = cur16; cur16 += (uint32_t)s.nt * s.kc16 * 2 * 64 * 8;
+        s.w16_off = cur16; cur16 += (uint32_t)s.nt * s.kc16() * 2 * 64 * 8;
         s.w_off = cur; cur += (uint32_t)s.nt * s.kc * 256;
         if (bias) { s.b_off = cur; cur += (uint32_t)s.nt * 32; } else s.b_off = 0xffffffffu;
         return s;
@@ -225,7 +230,7 @@ inline PackPlan build_pack_plan(const cfnerf_cfg& c, const ParamLayout& L) {
         PackDesc d{};
         d.src_off = (uint32_t)(e->off + (int64_t)row0 * e->cols + col0); d.src_ld = (uint32_t)e->cols; d.n_rows = (uint32_t)(nrows < 0 ? e->rows : nrows);
         d.n_cols = (uint32_t)ncols; d.dst_off = s.w_off; d.kc = s.kc; d.out_off = out_off; d.red_off = red_off;
-        d.dst16_off = s.w16_off; d.kc16 = s.kc16;
+        d.dst16_off = s.w16_off; d.kc16 = (uint32_t)s.kc16();
         d.transpose = transpose ? 1 : 0; d.first_elem = P.total_elems;
         P.total_elems += d.n_rows * d.n_cols;
         P.descs.push_back(d);

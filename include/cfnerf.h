@@ -16,7 +16,13 @@
  *     few KB of scratch, allocated in cfnerf_model_create.  A caller that hands in NO workspace gets a model-owned
  *     one that grows on demand (the only allocation outside create; it synchronises the device when it grows);
  *   - every launch is asynchronous on the hipStream_t passed in (pass torch's current stream); on the steady
- *     path (same N, S, K and workspace as the previous step) no entry point allocates, frees or synchronises;
+ *     path (same N, S, K and workspace as the previous step) no entry point allocates, frees or synchronises.
+ *     NOT steady: a caller that alternates two shapes on one model - the coarse + fine sampling EXTENSION of the host
+ *     mirror (train.Trainer.step_hierarchical: (N, 64, K) then (N, 192, K) every step) re-binds the one workspace twice
+ *     per step, so both of its cfnerf_render_bwd calls take the plan-rebuild path (weight-gradient descriptors rebuilt
+ *     and uploaded from double-buffered host copies, <= 300 MB of partials cleared: ~50 us each, asynchronous, but a host
+ *     sync when the model-owned workspace has to grow).  One plan slot per model is the contract; a caller that needs two
+ *     shapes at full speed uses two cfnerf_model handles, each re-packed from the one parameter buffer (cfnerf_model_set_params);
  *   - return value: 0 = OK, negative = cfnerf_status; cfnerf_last_error() gives a thread-local
  *     message.  No C++ exception crosses the ABI;
  *   - a handle lives on the device that was current at cfnerf_model_create (one handle per device, one

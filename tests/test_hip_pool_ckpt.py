@@ -44,6 +44,36 @@ def test_ray_pool_matches_get_rays_and_feeds_every_pixel_once_per_epoch():
     assert key(seen) == key(ref_rows)
 
 
+def test_sharded_device_pool_feeds_the_global_batch_across_an_epoch_boundary():
+    """RayPool(rank, world) on the device (rays from the product's kernel): four shards in the seed form (no exchange) - at every step the
+    concatenation of the shards is the batch the one-process pool with N_rand_global = 4 x 6 delivers; every pixel once per epoch."""
+    rng = np.random.default_rng(1)
+    V, H, W, focal = 3, 5, 7, 8.0
+    images = torch.tensor(rng.uniform(0, 1, (V, H, W, 3)), dtype=torch.float32)
+    poses = torch.zeros(V, 3, 4)
+    for v in range(V):
+        poses[v, :, :3] = torch.eye(3)
+        poses[v, :, 3] = torch.tensor(rng.uniform(-1, 1, 3))
+    world, n_rand = 4, 6
+    one = cfnerf_amd.RayPool(images, poses, H, W, focal, [0, 1, 2], N_rand=world * n_rand, seed=3)
+    shards = [cfnerf_amd.RayPool(images, poses, H, W, focal, [0, 1, 2], N_rand=n_rand, rank=r, world=world, seed=3, sync="seed") for r in range(world)]
+    assert len(one) == 105 and all(s.rays_rgb.is_cuda and torch.equal(s.rays_rgb, one.rays_rgb) for s in shards)
+    seen = []
+    for step in range(11):                                   # 105 = 4 x 24 + 9: the last window of an epoch is short and not a multiple of 4
+        rays1, tgt1 = one.next_batch()
+        got = [s.next_batch() for s in shards]
+        rays, tgt = torch.cat([g[0] for g in got], 1), torch.cat([g[1] for g in got], 0)
+        n = rays.shape[1]
+        assert n in (world * n_rand, 8) and all(g[0].shape[1] == n // world for g in got)
+        assert torch.equal(rays, rays1[:, :n]) and torch.equal(tgt, tgt1[:n])
+        assert all(s.epoch == one.epoch and s.i_batch == one.i_batch for s in shards)
+        if one.epoch == 0 or step < 5:
+            seen.append(tgt.cpu())
+    assert one.epoch == 2
+    first_epoch = torch.cat(seen[:5])                        # 4 full windows + the short one (8 of its 9 rays)
+    assert first_epoch.shape[0] == 104 and len({tuple(r) for r in first_epoch.numpy().round(6).tolist()}) == 104
+
+
 def test_checkpoint_roundtrip_in_the_reference_format():
     cfg = O.OracleCfg(netwidth=64, K_samples=2)
     _, kw_train, _, model, p, optimizer = build_model(cfg, 9)

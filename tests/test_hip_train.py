@@ -702,10 +702,13 @@ def test_one_hot_cotangent_reaches_every_ray_at_production_batch():
     base-Gaussian tensors of a full-batch gradient, and at N >= 1000 a reduction that dropped one ray would hide inside it).  Reference:
     the fp64 oracle on THAT ray only (a batch of one), on the ReLU masks the HIP forward took for its 128 points.  Rays at the edges of
     every partition the backward makes: the first / last of the batch, both sides of a 64-ray boundary, the middle, a random one.
-    Held to ONE_RAY_TOL of each tensor's largest entry: the base Gaussians (reduce_gms), every bias (reduce_bias), the heads and
-    flow heads (tail_bwd -> dw_small) and the trunk (bwd_data -> dw_big)."""
+    Held to ONE_RAY_TOL = 2e-5 of each tensor's largest entry: the base Gaussians (reduce_gms), every bias (reduce_bias), the heads and
+    flow heads (tail_bwd -> dw_small) and the trunk (bwd_data -> dw_big).  Where the SAME one-ray differentiation in fp32 on the CPU is
+    itself further than that from fp64 (the density path inside one ray still sums 128 x K terms of both signs through the transmittance
+    adjoint: measured up to ~1e-4 on alpha_mean for some rays), the bound is 8 x that measured fp32 noise, capped at ONE_RAY_CAP = 5e-4 -
+    three orders below the error of a dropped ray (1.0: with a one-hot cotangent the whole gradient IS this ray's)."""
     from util_hip import hip_relu_masks
-    ONE_RAY_TOL = 2e-5
+    ONE_RAY_TOL, ONE_RAY_CAP = 2e-5, 5e-4
     cfg = O.OracleCfg(netwidth=64, K_samples=4)
     _, kw_train, _, model, p, optimizer = build_model(cfg, 77)
     net = model.module
@@ -732,6 +735,10 @@ def test_one_hot_cotangent_reaches_every_ray_at_production_batch():
             r = O.render_rays(q, d(packed[i:i + 1]), cfg, d(ea), d(er), True, d(t_rand[i:i + 1]))
         close(rgbs[i:i + 1], r["rgb_map"].detach(), what=f"rgb_map of ray {i}")
         (r["rgb_map"] * d(Gi)[None]).sum().backward()
+        q32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}       # the same one-ray gradient in fp32: this case's conditioning
+        with O.relu_override(masks=masks):
+            r32 = O.render_rays(q32, packed[i:i + 1], cfg, ea, er, True, t_rand[i:i + 1])
+        (r32["rgb_map"] * Gi[None]).sum().backward()
         for key, (off, cnt) in net.layout.items():
             ref = q[key].grad
             got = g_hip[off:off + cnt]
@@ -740,9 +747,15 @@ def test_one_hot_cotangent_reaches_every_ray_at_production_batch():
                 continue
             ref = ref.reshape(-1)
             scale = float(ref.abs().max())
-            assert scale > 0, (i, key)
+            if scale == 0.0:                                   # flows_alpha.amor_d: fully masked at z = 1 (MOD:327,374) - exact zeros
+                assert key.startswith("flows_alpha.amor_d") and not got.any(), (i, key)
+                continue
             err = float((got - ref).abs().max()) / scale
-            worst[key] = max(worst.get(key, 0.0), err)
-            assert torch.all((got - ref).abs() <= ONE_RAY_TOL * scale + 1e-4 * ref.abs()), \
-                f"ray {i}, {key}: max error {err:.2e} of the largest entry exceeds {ONE_RAY_TOL:.0e}"
-    print("one-hot cotangent, worst error / largest entry per tensor:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+            noise32 = float((q32[key].grad.reshape(-1).double() - ref).abs().max()) / scale
+            tol = min(max(ONE_RAY_TOL, 8.0 * noise32), ONE_RAY_CAP)
+            if err > worst.get(key, (0.0,))[0]:
+                worst[key] = (err, noise32, i)
+            assert torch.all((got - ref).abs() <= tol * scale + 1e-4 * ref.abs()), \
+                f"ray {i}, {key}: max error {err:.2e} of the largest entry exceeds {tol:.1e} (fp32 CPU oracle on this ray: {noise32:.1e})"
+    print("one-hot cotangent, worst (error, fp32-oracle noise, ray) per tensor:",
+          {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2]) for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0])[:10]})

@@ -1,8 +1,8 @@
 #!/bin/bash
-# the bench lines of one round, one file per config (run on the GPU box through gpurun):  tools/bench_round.sh r03
+# the bench lines of one round, one file per config (run on the GPU box through gpurun):  tools/bench_round.sh r04
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run this through gpurun}"
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; T="${1:-r03}"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; T="${1:-r04}"; mkdir -p "$O"
 cd "$R"
 python bench.py > "$O/bench_${T}_default.json" 2> "$O/bench_${T}_default.err"
 B="--no-cpu-baseline --no-alt"
@@ -13,7 +13,9 @@ python bench.py $B --steps 50 --config C4 > "$O/bench_${T}_c4.json" 2>> "$O/benc
 python bench.py $B --steps 30 --config W512 > "$O/bench_${T}_w512.json" 2>> "$O/bench_${T}.err"
 python bench.py $B --steps 50 --config C1 > "$O/bench_${T}_c1.json" 2>> "$O/bench_${T}.err"
 python bench.py $B --steps 3 --warmup 1 --config C5 > "$O/bench_${T}_c5.json" 2>> "$O/bench_${T}.err"
-CFNERF_BENCH_SAME_GPU=1 python bench.py $B --gpus 2 --steps 20 > "$O/bench_${T}_2ranks_same_gpu.json" 2>> "$O/bench_${T}.err"
+python bench.py $B --steps 30 --config K64 > "$O/bench_${T}_k64.json" 2>> "$O/bench_${T}.err"
+# the N > 1 line with everything in it (psnr + vs_single_process, comm, rank_skew, cpu_baseline): two ranks on ONE GPU over gloo, a code-path run
+CFNERF_BENCH_SAME_GPU=1 python bench.py --gpus 2 --steps 20 --psnr-steps 500 > "$O/bench_${T}_2ranks_same_gpu.json" 2>> "$O/bench_${T}.err"
 for f in "$O"/bench_${T}_*.json; do python - "$f" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -10,10 +10,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
 
-for n, out in (("train", "train"), ("eval", "eval"), ("train_b16", "train_bf16x3"), ("w512", "w512_train"), ("c4", "c4_train"), ("c3", "c3_train")):
+for n, out in (("train", "train"), ("eval", "eval"), ("train_b16", "train_bf16x3"), ("w512", "w512_train"), ("c4", "c4_train"), ("c3", "c3_train"), ("k64", "k64_train")):
     src = os.path.join(G, f"i_{n}", f"{n}_kernel_stats.csv")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{out}_kernel_stats.csv"))

@@ -19,9 +19,10 @@ with tempfile.TemporaryDirectory() as d:
         j = blob.find(b"\x7fELF", i + 4)
         open(f"{d}/co{n}.elf", "wb").write(blob[i:j if j > 0 else len(blob)])
         out = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", f"{d}/co{n}.elf"], capture_output=True, text=True).stdout
-        for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", out, re.S):
-            agpr, lds, name, priv, sgpr, vgpr, spill = m.groups()
+        for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+)\s+\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", out, re.S):
+            agpr, lds, name, priv, sgpr, sspill, vgpr, spill = m.groups()
             dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-            print(f"{dem[:90]:90s} vgpr={vgpr:>3s} agpr={agpr:>3s} spill={spill:>3s} scratch={priv:>5s} lds={lds:>6s}")
+            dem = re.sub(r"\(.*\)$", "", dem).replace("void cfnerf::", "")
+            print(f"{dem[:60]:60s} vgpr={vgpr:>3s} agpr={agpr:>3s} vgpr_spill={spill:>3s} sgpr={sgpr:>3s} sgpr_spill={sspill:>3s} scratch={priv:>5s} lds={lds:>6s}")
         n += 1
         pos = i + 4

@@ -27,6 +27,7 @@ stats train_b16 --precision bf16x3
 stats w512 --config W512
 stats c4 --config C4
 stats c3 --config C3
+stats k64 --config K64
 pmc pmc_mfma "$SQ"
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
