@@ -572,16 +572,20 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
     [[maybe_unused]] const int64_t P = F(P0), n_tiles = F(n_tiles0);                                                           \
     [[maybe_unused]] float* const dbp = F(dbp0);                 /* this workgroup's bias-gradient partials */                 \
     [[maybe_unused]] const uint32_t* const mb_all = F(mb_all0)
-#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3: 222 spilt SGPRs at W = 256)
-    const BwdArgs& A = A_; const NetTab& T = T_;
-#define CFN_KEEP(x) (x)
-#define CFN_PHASE_ARGS CFN_PHASE_LOCALS(CFN_KEEP)
+    // Which scheme pays depends on the occupancy (round 4, same-box A/B of 200-step medians): with two workgroups per CU (W <= 256) the
+    // neighbour's MFMAs cover the constant-cache round trips and the ~650 v_readlane of the by-value scheme were the larger cost
+    // (backward-data 1.166 -> 1.159 ms at W = 256); with ONE workgroup per CU (W > 256: one wave per SIMD, nothing covers a scalar
+    // load) fetching per phase was 0.7 % SLOWER (2.215 -> 2.233 ms at W = 512), so the wide kernels keep the arguments by value.
+#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3 at every width: 222 spilt SGPRs at W = 256)
+    constexpr bool kKargMem = false;
 #else
-    (void)A_; (void)T_;
-#define CFN_KARGS const CFN_KCONST BwdKargs* kq_ = kernarg_fresh<BwdKargs>(); const CFN_KCONST BwdArgs& A = kq_->A; const CFN_KCONST NetTab& T = kq_->T
-#define CFN_PHASE_ARGS CFN_KARGS; CFN_PHASE_LOCALS(sgpr_fresh)
-    CFN_KARGS;
+    constexpr bool kKargMem = W <= 256;
 #endif
+#define CFN_KARGS const CFN_KCONST BwdKargs* kq_ = kernarg_fresh<BwdKargs, kKargMem>(); \
+                  auto& A = karg_pick<kKargMem>::get(kq_->A, A_); auto& T = karg_pick<kKargMem>::get(kq_->T, T_)
+#define CFN_FRESH(x) sgpr_fresh_if<kKargMem>(x)
+#define CFN_PHASE_ARGS CFN_KARGS; CFN_PHASE_LOCALS(CFN_FRESH)
+    CFN_KARGS;
     constexpr int LD = act_ld(W);
     constexpr int NT = W / 32, NTW = (NT + kWaves - 1) / kWaves, NTV = (W / 64 + kWaves - 1) / kWaves;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -727,7 +731,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
 #undef CFN_PHASE_ARGS
 #undef CFN_PHASE_LOCALS
 #undef CFN_KARGS
-#undef CFN_KEEP
+#undef CFN_FRESH
 }
 
 // ================================================================================================

@@ -34,12 +34,20 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // layer, the heads, the flows ...) takes a pointer to the kernarg segment that the optimiser cannot see through and s_loads what it
 // needs from the constant cache: scalar-unit work under the phase's first MFMAs, nothing live across phases.
 #define CFN_KCONST __attribute__((address_space(4)))
-template <class KA>
+template <class KA, bool FRESH = true>
 __device__ __forceinline__ const CFN_KCONST KA* kernarg_fresh() {
     const CFN_KCONST KA* p = (const CFN_KCONST KA*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
+    if (FRESH) asm volatile("" : "+s"(p));
     return p;
 }
+// one kernel source, either scheme per instantiation: the per-phase view of the kernarg segment or the by-value parameter itself
+template <bool MEM> struct karg_pick;
+template <> struct karg_pick<true> {
+    template <class S> static __device__ __forceinline__ const CFN_KCONST S& get(const CFN_KCONST S& mem, const S&) { return mem; }
+};
+template <> struct karg_pick<false> {
+    template <class S> static __device__ __forceinline__ const S& get(const CFN_KCONST S&, const S& by_value) { return by_value; }
+};
 // a wave-uniform value (an SGPR or an SGPR pair) the optimiser cannot see through from here on
 template <class V>
 __device__ __forceinline__ V sgpr_fresh(V v) {
@@ -55,6 +63,15 @@ __device__ __forceinline__ V* sgpr_fresh(V* p) {
     asm volatile("" : "+s"(g));
     return (V*)g;
 }
+template <bool FRESH, class V>
+__device__ __forceinline__ V sgpr_fresh_if(V v) { return FRESH ? sgpr_fresh(v) : v; }
+// "these scalars of a phase are fetched TOGETHER": every argument must be in its register here, so their s_loads are issued back to
+// back in front of ONE wait.  Left to itself the compiler puts each load at its value's first use with a full wait in front of that
+// use - a dependent chain of constant-cache round trips (~250 cycles each) through the phase.
+template <class V>
+__device__ __forceinline__ void sgpr_needed(const V& v) { asm volatile("" :: "s"(v)); }
+template <class... V>
+__device__ __forceinline__ void fetched_together(const V&... v) { (sgpr_needed(v), ...); }
 // by-value copy of a table entry out of the kernarg segment (scalar loads)
 template <class V>
 __device__ __forceinline__ V kload(const CFN_KCONST V& src) {

@@ -187,29 +187,36 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
 
             // ---- 1. sampling along the ray (RUN:510-534): z for rows 0..64, pts for rows 0..63
             if (MODE == 0) {
+                const float* const a_zin = A.z_in;
+                const float* const a_tv = A.t_vals;
+                const float* const a_tr = A.t_rand;
+                float* const a_pts = A.pts;
+                float* const a_stz = A.st_z;
+                const int a_flags = A.flags;
+                fetched_together(a_zin, a_tv, a_tr, a_pts, a_stz, a_flags);
                 if (tid <= kTileM) {
                     const int s = chunk * kTileM + tid;
                     float zv = 0.f, px = 0.f, py = 0.f, pz = 0.f;
                     if (s < S) {
-                        if (A.z_in != nullptr) {
-                            zv = A.z_in[unit * (int64_t)S + s];                                    // explicit depths (extension)
+                        if (a_zin != nullptr) {
+                            zv = a_zin[unit * (int64_t)S + s];                                     // explicit depths (extension)
                         } else {
-                            const bool lind = (A.flags & CFNERF_F_LINDISP) != 0;
-                            const float zc = zlin_f(A.t_vals[s], nearv, farv, lind);
+                            const bool lind = (a_flags & CFNERF_F_LINDISP) != 0;
+                            const float zc = zlin_f(a_tv[s], nearv, farv, lind);
                             zv = zc;
-                            if (A.t_rand != nullptr) {                                             // RUN:518-532
-                                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(A.t_vals[s + 1], nearv, farv, lind) + zc);
-                                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(A.t_vals[s - 1], nearv, farv, lind));
-                                zv = lower + (upper - lower) * A.t_rand[unit * (int64_t)S + s];
+                            if (a_tr != nullptr) {                                                 // RUN:518-532
+                                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(a_tv[s + 1], nearv, farv, lind) + zc);
+                                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(a_tv[s - 1], nearv, farv, lind));
+                                zv = lower + (upper - lower) * a_tr[unit * (int64_t)S + s];
                             }
                         }
                         px = ro[0] + rd[0] * zv; py = ro[1] + rd[1] * zv; pz = ro[2] + rd[2] * zv;  // RUN:534
                         if (tid < kTileM) {
-                            if (A.pts != nullptr) {
-                                float* o = A.pts + (unit * (int64_t)S + s) * 3;
+                            if (a_pts != nullptr) {
+                                float* o = a_pts + (unit * (int64_t)S + s) * 3;
                                 o[0] = px; o[1] = py; o[2] = pz;
                             }
-                            if (A.st_z != nullptr) A.st_z[unit * (int64_t)S + s] = zv;
+                            if (a_stz != nullptr) a_stz[unit * (int64_t)S + s] = zv;
                         }
                     }
                     float* ri = rowinfo + tid * 4;
@@ -229,6 +236,11 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             SubL tl_cur = kload(T.trunk[0]);
             SubL tl_nxt = kload((1 < Dn) ? T.trunk[1] : T.ft);
             const SubL tl_skip = kload(T.skipseg);
+            // ... and so do the stash destinations of the layer epilogues: this tile's rows of layer 0 + a per-layer stride, fetched here
+            // (four constant-cache round trips per layer when each field is loaded at its first use behind the epilogue's barrier)
+            float* const te_st0 = (A.st_h != nullptr) ? A.st_h + (size_t)p0 * W : nullptr;
+            uint32_t* const te_mb0 = (A.st_mbits != nullptr) ? A.st_mbits + (size_t)tile_idx * kMbStride : nullptr;
+            const size_t te_st_step = (size_t)A.P * W, te_mb_step = (size_t)A.n_tiles * kMbStride;
             load_bias<C::NTW>(tl_cur, wave, kWv, wp, bias_n);
             // ---- 2. positional encoding of the tile into act[:, 0:64)   (HLP:42-51, RUN:70-71)
             encode_tile<MODE, LD, PREC, kThr>(act, rowinfo, A.x, p0, rows_valid, ic, icv);
@@ -316,8 +328,8 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
                 __syncthreads();
                 CFN_MARK2();                         // all waves done with the MFMAs of this layer
-                float* st = (A.st_h != nullptr) ? A.st_h + ((size_t)l * A.P + p0) * W : nullptr;
-                uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)l * A.n_tiles + tile_idx) * kMbStride : nullptr;
+                float* st = (te_st0 != nullptr) ? te_st0 + (size_t)l * te_st_step : nullptr;
+                uint32_t* mb = (te_mb0 != nullptr) ? te_mb0 + (size_t)l * te_mb_step : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
                 store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
@@ -336,9 +348,13 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 CFN_PHASE_ARGS;
                 f32x16 accF[2][C::NTW];
                 f32x16 accA[2][1];
+                const SubL s_vf = kload(T.vf), s_ha = kload(T.ha);
+                float* const st_ha = A.st_ha;
+                float* const st_feat = A.st_feat;
+                fetched_together(s_vf.w_off, s_ha.w_off, st_ha, st_feat);
                 acc_init(accF, bias_n); acc_zero(accA);
-                load_bias<C::NTV>(kload(T.vf), wave, kWv, wp, bias_v);
-                mma_ksplit<PREC, 2>(accA, kload(T.ha), wave, kWv, wp, wp16, act, LD);
+                load_bias<C::NTV>(s_vf, wave, kWv, wp, bias_v);
+                mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
                 mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();                     // every wave is done reading h
                 {
@@ -351,23 +367,23 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
                 __syncthreads();
                 {
-                    const int ntc = (int)T.ha.nt, nparts = kWv / ntc;
+                    const int ntc = (int)s_ha.nt, nparts = kWv / ntc;
                     for (int idx = tid; idx < kTileM * HA; idx += kThr) {
                         const int row = idx / HA, c = idx - row * HA;
                         const float* pp = act + row * LD + 32 * (c >> 5) + (c & 31);     // wave w = part * ntc + n-tile
                         float v = pp[0];
                         for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
-                        v += wp[T.ha.b_off + c];
+                        v += wp[s_ha.b_off + c];
                         act_store<PREC>(hs + row * HLD, HLD, c, v);
-                        if (A.st_ha != nullptr && row < rows_valid) st_stream(A.st_ha + (p0 + row) * HA + c, v);
+                        if (st_ha != nullptr && row < rows_valid) st_stream(st_ha + (p0 + row) * HA + c, v);
                     }
                 }
                 __syncthreads();
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
                 store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, tl_ft, wave, kWv, wp, act, LD, 0,
-                                              A.st_feat ? A.st_feat + p0 * W : nullptr, W, rows_valid);
+                                              st_feat ? st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
-                if (kRows && A.st_feat != nullptr) stash_rows<W, kThr>(act, LD, A.st_feat + p0 * W, rows_valid);
+                if (kRows && st_feat != nullptr) stash_rows<W, kThr>(act, LD, st_feat + p0 * W, rows_valid);
             }
             CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
@@ -375,9 +391,13 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             {
                 CFN_PHASE_ARGS;
                 f32x16 acc[2][C::NTV];
+                const SubL s_hr = kload(T.hr), s_vf = kload(T.vf), s_vd = kload(T.vd);
+                float* const st_gd = A.st_gd;
+                float* const st_v = A.st_v;
+                fetched_together(s_hr.w_off, s_vf.w_off, s_vd.w_off, st_gd, st_v);
                 acc_init(acc, bias_v);
-                load_bias<1>(kload(T.hr), wave, kWv, wp, bias_h);
-                mma_any<C::NTV, PREC, 2>(acc, kload(T.vf), wave, kWv, wp, wp16, act, LD);
+                load_bias<1>(s_hr, wave, kWv, wp, bias_h);
+                mma_any<C::NTV, PREC, 2>(acc, s_vf, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 for (int idx = tid; idx < kTileM * 32; idx += kThr) {
                     const int row = idx >> 5, c = idx & 31;
@@ -385,28 +405,31 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     if (MODE == 0) v = gdir[c];
                     else v = (c < icv && row < rows_valid) ? A.x[(p0 + row) * (int64_t)(ic + icv) + ic + c] : 0.f;
                     act_store<PREC>(act + row * LD, LD, c, v);
-                    if (A.st_gd != nullptr && row < rows_valid) st_stream(A.st_gd + (p0 + row) * 32 + c, v);
+                    if (st_gd != nullptr && row < rows_valid) st_stream(st_gd + (p0 + row) * 32 + c, v);
                 }
                 __syncthreads();
-                mma_any<C::NTV, PREC, 2>(acc, kload(T.vd), wave, kWv, wp, wp16, act, LD);
+                mma_any<C::NTV, PREC, 2>(acc, s_vd, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
-                uint32_t* mb = (A.st_mbits != nullptr) ? A.st_mbits + ((size_t)T.D * A.n_tiles + tile_idx) * kMbStride : nullptr;
+                uint32_t* mb = (te_mb0 != nullptr) ? te_mb0 + (size_t)Dn * te_mb_step : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, kload(T.vf), wave, kWv, wp, act, LD, 0,
-                                                    A.st_v ? A.st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, s_vf, wave, kWv, wp, act, LD, 0,
+                                                    st_v ? st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
-                if (kRows && A.st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, A.st_v + p0 * (W / 2), rows_valid);
+                if (kRows && st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, st_v + p0 * (W / 2), rows_valid);
             }
             CFN_MARK();                              // views done
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 CFN_PHASE_ARGS;
                 f32x16 acc[2][1];
+                const SubL s_hr = kload(T.hr);
+                float* const st_hr = A.st_hr;
+                fetched_together(s_hr.w_off, st_hr);
                 acc_init(acc, bias_h);
-                mma_any<1, PREC, 2>(acc, kload(T.hr), wave, kWv, wp, wp16, act, LD);
+                mma_any<1, PREC, 2>(acc, s_hr, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
-                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, kload(T.hr), wave, kWv, wp, act, LD, W / 2,
-                                         A.st_hr ? A.st_hr + p0 * HR : nullptr, HR, rows_valid);
+                store_tiles<1, ACT_NONE, PREC, false, TRAIN, true>(acc, s_hr, wave, kWv, wp, act, LD, W / 2,
+                                         st_hr ? st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
             CFN_MARK();                              // h_rgb done
@@ -418,9 +441,12 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 acc_zero(acc);
                 const bool is_rgb = wave < 3;               // waves 0-2: the three rgb n-tiles; wave 3: alpha; others idle
                 const bool is_theta = wave < 4;
-                const float bv = wp[(is_rgb ? T.fr.b_off + wave * 32 : T.fa.b_off) + (lane_id_opaque() & 31)];   // lands under the MFMAs
-                if (is_rgb)        mma_any<1, PREC, 2>(acc, kload(T.fr), wave, kWv, wp, wp16, act, LD, W / 2);
-                else if (is_theta) mma_any<1, PREC, 2>(acc, kload(T.fa), 0, kWv, wp, wp16, hs, HLD);
+                const SubL s_fr = kload(T.fr), s_fa = kload(T.fa);
+                float* const st_theta = A.st_theta;
+                fetched_together(s_fr.w_off, s_fa.w_off, st_theta);
+                const float bv = wp[(is_rgb ? s_fr.b_off + wave * 32 : s_fa.b_off) + (lane_id_opaque() & 31)];   // lands under the MFMAs
+                if (is_rgb)        mma_any<1, PREC, 2>(acc, s_fr, wave, kWv, wp, wp16, act, LD, W / 2);
+                else if (is_theta) mma_any<1, PREC, 2>(acc, s_fa, 0, kWv, wp, wp16, hs, HLD);
                 __syncthreads();
                 const int colb = is_rgb ? wave * 32 : kThetaRgb;
                 const int lo = lane_id_opaque();
@@ -431,8 +457,8 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 float* lp = act + rbase * LD + colb + cl;
                 // stash through a slab descriptor over the tile's valid rows (scalar row offsets, ragged rows dropped by the bounds
                 // check): one code path, no 64-bit address arithmetic per element (quarter-rate on this chip)
-                const bool stash = TRAIN && A.st_theta != nullptr;              // wave-uniform
-                const __amdgpu_buffer_rsrc_t sink = slab_rsrc(stash ? A.st_theta + p0 * kThetaAll : nullptr, stash ? rows_valid : 0, kThetaAll);
+                const bool stash = TRAIN && st_theta != nullptr;                // wave-uniform
+                const __amdgpu_buffer_rsrc_t sink = slab_rsrc(stash ? st_theta + p0 * kThetaAll : nullptr, stash ? rows_valid : 0, kThetaAll);
                 const int voff = (rbase * kThetaAll + colb + cl) * 4;
                 if (is_theta) {
 #pragma unroll
@@ -452,6 +478,12 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             // ---- 8. flows + composite: lane = sample (row), waves stride over the K latent samples
             {
                 CFN_PHASE_ARGS;
+                const float* const f_eps = A.eps;
+                float* const f_raw = A.raw;
+                float* const f_weights = A.weights;
+                float* const f_at = A.st_at;
+                const int f_flags = A.flags;
+                fetched_together(f_eps, f_raw, f_weights, f_at, f_flags);
                 const int row = lane_id_opaque();
                 const bool valid = row < rows_valid;
                 float th[84];
@@ -480,14 +512,14 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     using M = Num<FAST>;
                     for (int k = wave; k < K; k += kWv) {
-                        const f32x4 e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
+                        const f32x4 e = *reinterpret_cast<const f32x4*>(f_eps + k * 4);
                         float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
                         float a = e[3] * a_std + a_mean;                                               // MOD:200/239
                         float ldr, lda;
                         flows_fwd<TRAIN, FAST>(th, z, a, ldr, lda);
-                        if (A.raw != nullptr && valid) {
+                        if (f_raw != nullptr && valid) {
                             f32x4 o; o[0] = z[0]; o[1] = z[1]; o[2] = z[2]; o[3] = a;
-                            *reinterpret_cast<f32x4*>(A.raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
+                            *reinterpret_cast<f32x4*>(f_raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
                         }
                         const float sp_a = M::softplus(a);
                         if (TRAIN && valid) {
@@ -502,10 +534,10 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                             float* cp = comp + k * 8;
                             const float Tcar = cp[5];
                             const float wgt = alpha * (Tcar * excl);
-                            if (A.weights != nullptr && valid) A.weights[(p0 + row) * (int64_t)K + k] = wgt;
-                            if (A.st_at != nullptr && valid) {
+                            if (f_weights != nullptr && valid) f_weights[(p0 + row) * (int64_t)K + k] = wgt;
+                            if (f_at != nullptr && valid) {
                                 f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
-                                *reinterpret_cast<f32x2*>(A.st_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
+                                *reinterpret_cast<f32x2*>(f_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
                             }
                             const float s0 = comp_sum(wgt * M::sigmoid(z[0]));                         // RUN:431,444
                             const float s1 = comp_sum(wgt * M::sigmoid(z[1]));
@@ -519,7 +551,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                         }
                     }
                 };
-                const bool fast = (A.flags & CFNERF_F_FLOW_MATH_SET) ? (A.flags & CFNERF_F_FLOW_MATH_FAST) != 0 : K >= kFastFlowsK;     // wave-uniform
+                const bool fast = (f_flags & CFNERF_F_FLOW_MATH_SET) ? (f_flags & CFNERF_F_FLOW_MATH_FAST) != 0 : K >= kFastFlowsK;     // wave-uniform
                 if (fast) flow_phase(std::true_type{});
                 else flow_phase(std::false_type{});
             }
