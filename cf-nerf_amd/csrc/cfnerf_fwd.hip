@@ -287,14 +287,22 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
 
             CFN_MARK();                              // encoding done
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
+#ifdef CFN_ACC_EARLY     // (A/B builds, round 4) the accumulators take the next layer's bias BEFORE the stash copy-out of this layer is issued
+            f32x16 acc[2][C::NTW];
+            acc_init(acc, bias_n);
+#endif
             for (int l = 0; l < Dn; ++l) {
                 CFN_PHASE_ARGS;
+#ifndef CFN_ACC_EARLY
                 f32x16 acc[2][C::NTW];
+#endif
                 const SubL tl_nn = kload((l + 2 < Dn) ? T.trunk[l + 2] : T.ft);                 // (in flight under this layer's MFMAs)
+#ifndef CFN_ACC_EARLY
                 acc_init(acc, bias_n);
                 // the accumulators take the bias fetched a layer ago (its wait also drains the previous layer's stash stores: one counter);
                 // only THEN is the next layer's bias requested - hoisted above that wait it would expose an L2 round trip per layer
                 asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][C::NTW - 1][0]) : "memory");
+#endif
                 load_bias<C::NTW>(tl_nxt, wave, kWv, wp, bias_n);                               // next layer's / the feature head's
                 CFN_MARK();                          // MFMA phase of layer l starts
                 mma_any<C::NTW, PREC, 2>(acc, tl_cur, wave, kWv, wp, wp16, act, LD);
@@ -334,6 +342,10 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
                 CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
+#ifdef CFN_ACC_EARLY
+                acc_init(acc, bias_n);               // (the next layer's / the feature head's; fetched at this layer's top)
+                asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][C::NTW - 1][0]) : "memory");
+#endif
                 if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
                 CFN_MARK();                          // epilogue + barrier done
                 tl_cur = tl_nxt; tl_nxt = tl_nn;
@@ -346,13 +358,20 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             float bias_v[C::NTV];                    // views-layer bias, in flight during the heads
             {
                 CFN_PHASE_ARGS;
+#ifdef CFN_ACC_EARLY
+                auto& accF = acc;
+#else
                 f32x16 accF[2][C::NTW];
+#endif
                 f32x16 accA[2][1];
                 const SubL s_vf = kload(T.vf), s_ha = kload(T.ha);
                 float* const st_ha = A.st_ha;
                 float* const st_feat = A.st_feat;
                 fetched_together(s_vf.w_off, s_ha.w_off, st_ha, st_feat);
-                acc_init(accF, bias_n); acc_zero(accA);
+#ifndef CFN_ACC_EARLY
+                acc_init(accF, bias_n);
+#endif
+                acc_zero(accA);
                 load_bias<C::NTV>(s_vf, wave, kWv, wp, bias_v);
                 mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
                 mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r03"
+TAG = "r04"
 
 
 def line(name):
@@ -18,7 +18,7 @@ def line(name):
 
 
 @pytest.mark.parametrize("name,workload", [("default", "C2"), ("c2", "C2"), ("c3", "C3"), ("c4", "C4"), ("w512", "W512"), ("eval", "C2"), ("c5", "C5"), ("c1", "C1"),
-                                           ("2ranks_same_gpu", "C2")])
+                                           ("k64", "K64"), ("2ranks_same_gpu", "C2")])
 def test_bench_lines_carry_the_contract(name, workload):
     d = line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -26,8 +26,17 @@ def test_bench_lines_carry_the_contract(name, workload):
         assert k in d, (name, k)
     assert d["config"]["workload"].startswith(workload) and d["unit"] == "rays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
     r = d["roofline"]
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.4 < r["frac"] < 1.0
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    if name == "2ranks_same_gpu":
+        # round 4: the N > 1 line explains itself (two ranks on ONE GPU over gloo: a code-path run, not a scaling number)
+        assert d["n_gpus"] == 2 and d["comm"]["world_size_reported"] == 2 and d["comm"]["backend"] == "gloo" and d["comm"]["exposed_ms_mean"] > 0
+        assert d["rank_skew"]["ms_per_step_min"] <= d["rank_skew"]["ms_per_step_max"] and d["cpu_baseline"]["value"] > 0
+        p = d["psnr"]
+        assert p["n_gpus"] == 2 and p["global_batch"] == 2048 and p["vs_single_process"]["agree"] is True and p["vs_single_process"]["abs_psnr_diff_db"] <= 0.05
+        assert p["vs_oracle"]["agree"] is True and p["vs_reference_run"]["agree"] is True
+    if name == "k64":
+        assert "K=64" in d["config"]["workload"] and d["kernel_ms"]["bwd_tail"] > 0.15      # the reference's default latent count (RUN:631)
     if name == "default":
         assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and "alt_precision" in d and "stress_w512" in d
         # the second half of the headline metric, in the line itself (synthetic stand-in scene) + the HIP-vs-oracle agreement
