@@ -10,7 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcfnerf_hip.so")
 CONSUMER = os.path.join(OBJ, "abi_consumer")
-SOURCES = ["cfnerf_fwd.hip", "cfnerf_bwd.hip", "cfnerf_abi.hip"]
+SOURCES = ["cfnerf_fwd.hip", "cfnerf_bwd.hip", "cfnerf_tail.hip", "cfnerf_abi.hip"]
+# per-file flags: the flow-adjoint kernels are long straight-line scalar code that the SLP vectoriser makes slower (cfnerf_tail.hip)
+EXTRA_FLAGS = {"cfnerf_tail.hip": ["-fno-slp-vectorize"]}
 # -ffp-contract=off: the sampling / encoding arithmetic must round like the reference's separate
 # torch ops (an fma in pts = o + d*z moves sin(2^9 x) by ~3e-5); MFMA code is unaffected.
 # -fvisibility=hidden: the dynamic symbol table holds the CFNERF_API entry points of include/cfnerf.h (+ the test hooks of
@@ -43,14 +45,14 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):

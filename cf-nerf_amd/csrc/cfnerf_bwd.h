@@ -32,6 +32,11 @@ struct BwdArgs {
     int32_t db_h, db_feat, db_v, db_ha, db_hr, db_theta;  // column offsets inside a dbp row
 };
 
+// the flow-adjoint kernels live in cfnerf_tail.hip (a translation unit compiled without the SLP vectoriser)
+hipError_t launch_tail_bwd(const TailArgs& ta, int64_t n_rays, int ksplit, hipStream_t st);
+hipError_t launch_flows_bwd(const float* raw, const float* theta, const float* eps, const float* flat, const float* d_raw, const float* d_ent,
+                            int64_t P, int K, float* g_theta, float* gms_partials, unsigned* grid_out, hipStream_t st);
+
 // one 128 x 256 output tile of a weight-gradient job  dW[n][k] = sum_p dY[p][n] * X[p][k]
 struct DwTile {
     const float* dY; int32_t ldY, N, Npad;                // Npad: readable width of a dY row from the slice start

@@ -11,11 +11,11 @@ O="$R/cf-nerf_amd/build/asan"; mkdir -p "$O"
 RT="$(dirname "$(hipcc --offload-arch=gfx950 -print-file-name=libclang_rt.asan-x86_64.so 2>/dev/null || true)")"
 [ -f "$RT/libclang_rt.asan-x86_64.so" ] || RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux
 F="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-result -Wno-unused-value -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
-for f in cfnerf_fwd cfnerf_bwd cfnerf_abi; do
+for f in cfnerf_fwd cfnerf_bwd cfnerf_tail cfnerf_abi; do
   hipcc $F "-DCFN_FOR_EACH_WIDTH(X)=X(256)" -c "$R/cf-nerf_amd/csrc/$f.hip" -o "$O/$f.o" &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -o "$R/cf-nerf_amd/libvar_asan.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_abi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -o "$R/cf-nerf_amd/libvar_asan.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_tail.o "$O"/cfnerf_abi.o
 cd "$R"
 LOG="$O/asan_run.log"
 CFNERF_LIB="$R/cf-nerf_amd/libvar_asan.so" LD_LIBRARY_PATH="$RT:${LD_LIBRARY_PATH:-}" LD_PRELOAD="$RT/libclang_rt.asan-x86_64.so" \

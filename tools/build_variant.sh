@@ -9,6 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility
 for f in cfnerf_fwd cfnerf_bwd cfnerf_abi; do
   hipcc $FLAGS "$@" -c "$R/cf-nerf_amd/csrc/$f.hip" -o "$O/$f.o" &
 done
+hipcc $FLAGS -fno-slp-vectorize "$@" -c "$R/cf-nerf_amd/csrc/cfnerf_tail.hip" -o "$O/cfnerf_tail.o" &      # (per-file flag: see cf-nerf_amd/build.py)
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -o "$R/cf-nerf_amd/libvar_$name.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_abi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -o "$R/cf-nerf_amd/libvar_$name.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_tail.o "$O"/cfnerf_abi.o
 echo "$R/cf-nerf_amd/libvar_$name.so"
