@@ -30,6 +30,12 @@ namespace cfnerf {
 //    finalize kernel then turns into [loss, loss_nll, mse, psnr].  (A single 1024-thread workgroup took 87 us at K = 16.)
 constexpr double kLossFix = 68719476736.0;      // 2^36: resolution 1.5e-11 per workgroup partial, |sum| < 3.3e7
 constexpr int kLossThreads = 256;
+// L lanes share one (ray, channel) row of K values (lane `sub` takes k = sub, sub + L, ...; sums meet through an L-wide xor butterfly).
+// L = 1 is the kernel of rounds 1-3, operation for operation - every K below kLossWideK (the reference's plumbing and headline
+// configurations) runs it.  L = 8 from kLossWideK latents on: one thread per row walks 2 K correctly rounded expf serially on 12
+// workgroups (39 us at the reference's default K = 64, 22 at K = 32); eight lanes per row are 96 workgroups of K / 8-step loops.
+constexpr int kLossWideK = 16;
+template <int L>
 __global__ __launch_bounds__(kLossThreads)
 void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, int64_t N, int K, int64_t n_total,
                  float* __restrict__ d_rgb, long long* __restrict__ acc) {
@@ -39,27 +45,39 @@ void loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target
     const float c2pi = powf(2.f * 3.14159265358979323846f, -1.5f);      // RUN:1039
     const float gscale = 1.f / (3.f * (float)n_total);
     double nll = 0.0, mse = 0.0;
-    const int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
-    if (i < N * 3) {
-        const float* x = rgb + i * K;                                   // [N,3,K]: (n,c) row of K values
-        const float t = target[i];
-        float mean = 0.f;
-        for (int k = 0; k < K; ++k) mean += x[k];
-        mean *= invK;                                                   // RUN:1027
-        float var = 0.f;
-        for (int k = 0; k < K; ++k) { const float d = x[k] - mean; var += d * d; }
-        const float sd = sqrtf(var / (float)(K - 1));                   // torch.std (unbiased); K == 1 -> NaN like the reference (R4)
-        const float rgb_std = sd * (float)K / (float)(K - 1);           // RUN:1034
-        const float H = rgb_std * bw + 1e-05f;                          // RUN:1036 (detached)
-        const float c2 = c2pi / H;                                      // RUN:1039
-        const float inv2h2 = 1.f / (2.f * H * H);
-        float rsum = 0.f;
-        for (int k = 0; k < K; ++k) { const float d = x[k] - t; rsum += expf(-(d * d) * inv2h2) * c2; }
-        const float m = rsum * invK + 1e-05f;                           // RUN:1041
-        nll = -logf(m);                                                 // RUN:1042
-        mse = (double)((mean - t) * (mean - t));                        // RUN:1028
+    const int64_t t_idx = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
+    const int64_t i = t_idx / L;
+    const int sub = (int)(t_idx - i * L);
+    auto group_sum = [](float v) {
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) v += __shfl_xor(v, d, 64);
+        return v;
+    };
+    const bool live = i < N * 3;                                        // (a row's L lanes sit in one wave: live is uniform over them)
+    const float* x = rgb + (live ? i : 0) * K;                          // [N,3,K]: (n,c) row of K values
+    const float t = live ? target[i] : 0.f;
+    float mean = 0.f;
+    for (int k = sub; k < K; k += L) mean += x[k];
+    mean = group_sum(mean) * invK;                                      // RUN:1027
+    float var = 0.f;
+    for (int k = sub; k < K; k += L) { const float d = x[k] - mean; var += d * d; }
+    var = group_sum(var);
+    const float sd = sqrtf(var / (float)(K - 1));                       // torch.std (unbiased); K == 1 -> NaN like the reference (R4)
+    const float rgb_std = sd * (float)K / (float)(K - 1);               // RUN:1034
+    const float H = rgb_std * bw + 1e-05f;                              // RUN:1036 (detached)
+    const float c2 = c2pi / H;                                          // RUN:1039
+    const float inv2h2 = 1.f / (2.f * H * H);
+    float rsum = 0.f;
+    for (int k = sub; k < K; k += L) { const float d = x[k] - t; rsum += expf(-(d * d) * inv2h2) * c2; }
+    rsum = group_sum(rsum);
+    const float m = rsum * invK + 1e-05f;                               // RUN:1041
+    if (live) {
+        if (sub == 0) {
+            nll = -logf(m);                                             // RUN:1042
+            mse = (double)((mean - t) * (mean - t));                    // RUN:1028
+        }
         const float gcoef = gscale * invK / (m * H * H);
-        for (int k = 0; k < K; ++k) {
+        for (int k = sub; k < K; k += L) {
             const float d = x[k] - t;
             d_rgb[i * K + k] = gcoef * (expf(-(d * d) * inv2h2) * c2) * d;
         }
@@ -1260,8 +1278,12 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
     if (reinterpret_cast<uintptr_t>(scalars_out) % 8) return bfail(CFNERF_E_INVALID, "scalars_out must be 8-byte aligned");
     hipStream_t st = (hipStream_t)s;
     BHIP(hipMemsetAsync(scalars_out, 0, 4 * sizeof(float), st));        // the two 64-bit fixed-point accumulators live in these 16 bytes
-    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((N * 3 + kLossThreads - 1) / kLossThreads)), dim3(kLossThreads), 0, st, rgb_map, target,
-                       N, K, n_total, d_rgb_map, reinterpret_cast<long long*>(scalars_out));
+    if (K >= kLossWideK)
+        hipLaunchKernelGGL(loss_kernel<8>, dim3((unsigned)((N * 3 * 8 + kLossThreads - 1) / kLossThreads)), dim3(kLossThreads), 0, st, rgb_map, target,
+                           N, K, n_total, d_rgb_map, reinterpret_cast<long long*>(scalars_out));
+    else
+        hipLaunchKernelGGL(loss_kernel<1>, dim3((unsigned)((N * 3 + kLossThreads - 1) / kLossThreads)), dim3(kLossThreads), 0, st, rgb_map, target,
+                           N, K, n_total, d_rgb_map, reinterpret_cast<long long*>(scalars_out));
     BHIP(hipGetLastError());
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, entropy, beta1, n_total, scalars_out);
     BHIP(hipGetLastError());

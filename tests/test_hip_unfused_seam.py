@@ -225,6 +225,40 @@ def test_chunked_custom_query_fn_trains_through_the_one_stash():
             assert _rel_to_max(a, b) <= 2e-5, (key, _rel_to_max(a, b))       # chunk-wise partial sums of dW: order of summation only
 
 
+def test_a_replaced_stash_is_not_recomputed_at_changed_weights():
+    """Two grad-enabled network calls: the second replaces the model's one stash, so the first node's backward would re-run its forward.
+    If the parameters changed in between (an optimizer step between the chunk backwards, a retained graph reused after an update) that
+    re-run is a DIFFERENT function: it must raise like torch autograd ("modified by an inplace operation"), not differentiate silently at
+    the new weights (round-3 advisor).  Unchanged parameters: the re-run is taken and gives the first call's own gradient."""
+    cfg, args, kw_train, model, p, rays, (H, Wd, focal), t_rand, ea, er, target = _problem(64, 3, 8, seed=5)
+    net = model.module
+    rng = np.random.default_rng(0)
+    xa = torch.tensor(rng.standard_normal((200, 90)), dtype=torch.float32, device=DEV)
+    xb = torch.tensor(rng.standard_normal((300, 90)), dtype=torch.float32, device=DEV)
+    # reference gradient of the first call alone
+    net.flat.grad = None
+    ra, _ = net(xa, eps_alpha=ea, eps_rgb=er)
+    ra.sum().backward()
+    g_alone = net.flat.grad.clone()
+    # the same call, its stash replaced by a second one, parameters untouched: re-run forward, same gradient
+    net.flat.grad = None
+    ra, _ = net(xa, eps_alpha=ea, eps_rgb=er)
+    rb, _ = net(xb, eps_alpha=ea, eps_rgb=er)
+    ra.sum().backward()
+    assert torch.equal(net.flat.grad, g_alone)
+    # ... and with the parameters updated in place between the forward and its backward: refused
+    net.flat.grad = None
+    ra, _ = net(xa, eps_alpha=ea, eps_rgb=er)
+    rb, _ = net(xb, eps_alpha=ea, eps_rgb=er)
+    with torch.no_grad():
+        net.flat.add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        ra.sum().backward()
+    # the newest call still has its stash (activations AND packed weights of the forward it recorded): its backward needs no re-run
+    rb.sum().backward()
+    assert torch.isfinite(net.flat.grad).all()
+
+
 def test_three_optimizer_steps_through_the_unfused_path_follow_the_fused_path():
     """create_nerf's own torch.optim.Adam over grad_vars (RUN:339), loss.backward(), optimizer.step() - the reference's loop
     verbatim - through a custom query fn and through the fused launch: same parameters after three steps."""

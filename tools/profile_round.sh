@@ -15,7 +15,7 @@ B="--no-cpu-baseline --no-alt"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"
 stats() {  # name, bench args
   local n="$1"; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/i_$n" -o "$n" -- python3 "$R/bench.py" --steps 20 --warmup 3 $B "$@" > "$O/i_$n.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/i_$n" -o "$n" -- python3 "$R/bench.py" --steps 50 --warmup 3 $B "$@" > "$O/i_$n.log" 2>&1
 }
 pmc() {    # name, counters, bench args
   local n="$1" c="$2"; shift 2
