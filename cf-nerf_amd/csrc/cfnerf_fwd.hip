@@ -387,14 +387,33 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 __syncthreads();
                 {
                     const int ntc = (int)s_ha.nt, nparts = kWv / ntc;
-                    for (int idx = tid; idx < kTileM * HA; idx += kThr) {
-                        const int row = idx / HA, c = idx - row * HA;
-                        const float* pp = act + row * LD + 32 * (c >> 5) + (c & 31);     // wave w = part * ntc + n-tile
-                        float v = pp[0];
-                        for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
-                        v += wp[s_ha.b_off + c];
-                        act_store<PREC>(hs + row * HLD, HLD, c, v);
-                        if (st_ha != nullptr && row < rows_valid) st_stream(st_ha + (p0 + row) * HA + c, v);
+                    if (kThr % HA == 0) {
+                        // (round 4) every thread owns ONE column (the thread count is a multiple of h_alpha_size: 32, 64, 128): its bias is
+                        // fetched once, in front of the loop.  Element by element - `wp[b_off + c]` inside the loop - the compiler emitted
+                        // global_load, s_waitcnt vmcnt(0), add, ds_write, store per element: a serialised L2 round trip (which also drains the
+                        // previous element's stash store) 8 ... 32 times per tile, plus an integer division by the run-time HA each.
+                        // Same element -> thread map, same order of the partial sums.
+                        const int c = tid % HA, rstep = kThr / HA;
+                        const float bc = wp[s_ha.b_off + c];
+                        const float* pp0 = act + 32 * (c >> 5) + (c & 31);                   // wave w = part * ntc + n-tile
+                        for (int row = tid / HA; row < kTileM; row += rstep) {
+                            const float* pp = pp0 + row * LD;
+                            float v = pp[0];
+                            for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
+                            v += bc;
+                            act_store<PREC>(hs + row * HLD, HLD, c, v);
+                            if (st_ha != nullptr && row < rows_valid) st_stream(st_ha + (p0 + row) * HA + c, v);
+                        }
+                    } else {
+                        for (int idx = tid; idx < kTileM * HA; idx += kThr) {
+                            const int row = idx / HA, c = idx - row * HA;
+                            const float* pp = act + row * LD + 32 * (c >> 5) + (c & 31);
+                            float v = pp[0];
+                            for (int q = 1; q < nparts; ++q) v += pp[32 * ntc * q];
+                            v += wp[s_ha.b_off + c];
+                            act_store<PREC>(hs + row * HLD, HLD, c, v);
+                            if (st_ha != nullptr && row < rows_valid) st_stream(st_ha + (p0 + row) * HA + c, v);
+                        }
                     }
                 }
                 __syncthreads();
