@@ -198,16 +198,24 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     const int s = chunk * kTileM + tid;
                     float zv = 0.f, px = 0.f, py = 0.f, pz = 0.f;
                     if (s < S) {
+                        // every input of this sample is requested before the first is used (round 4): written as nested conditionals the
+                        // loads sat behind one another, each with its own full wait - four serialised memory round trips at every tile
+                        // start, with 191 of the workgroup's 256 threads waiting at the barrier below.  Same arithmetic.
+                        const int64_t si = unit * (int64_t)S + s;
+                        const float tv0 = a_tv[s], tvp = a_tv[min(s + 1, S - 1)], tvm = a_tv[max(s - 1, 0)];
+                        float trv = 0.f, zin = 0.f;
+                        if (a_tr != nullptr) trv = a_tr[si];
+                        if (a_zin != nullptr) zin = a_zin[si];
                         if (a_zin != nullptr) {
-                            zv = a_zin[unit * (int64_t)S + s];                                     // explicit depths (extension)
+                            zv = zin;                                                              // explicit depths (extension)
                         } else {
                             const bool lind = (a_flags & CFNERF_F_LINDISP) != 0;
-                            const float zc = zlin_f(a_tv[s], nearv, farv, lind);
+                            const float zc = zlin_f(tv0, nearv, farv, lind);
                             zv = zc;
                             if (a_tr != nullptr) {                                                 // RUN:518-532
-                                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(a_tv[s + 1], nearv, farv, lind) + zc);
-                                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(a_tv[s - 1], nearv, farv, lind));
-                                zv = lower + (upper - lower) * a_tr[unit * (int64_t)S + s];
+                                const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(tvp, nearv, farv, lind) + zc);
+                                const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(tvm, nearv, farv, lind));
+                                zv = lower + (upper - lower) * trv;
                             }
                         }
                         px = ro[0] + rd[0] * zv; py = ro[1] + rd[1] * zv; pz = ro[2] + rd[2] * zv;  // RUN:534
