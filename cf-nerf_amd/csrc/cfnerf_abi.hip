@@ -47,6 +47,9 @@ static int model_init_device(cfnerf_model* m) {
     HIPCHK(hipMemset(m->d_packed16, 0, (size_t)m->plan.tab.packed16_elems * 2));
     HIPCHK(hipMalloc(&m->d_descs, m->plan.descs.size() * sizeof(PackDesc)));
     HIPCHK(hipMemcpy(m->d_descs, m->plan.descs.data(), m->plan.descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&m->d_pack_table, (size_t)m->plan.total_elems * 3 * sizeof(uint32_t)));
+    HIPCHK(launch_pack_index(m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, m->d_pack_table, nullptr));
+    HIPCHK(hipDeviceSynchronize());
     m->ent_cap = fused_fwd_max_grid(cfg->netwidth, cfg->h_alpha_size, m->n_cu);
     HIPCHK(hipMalloc(&m->d_ent_partials, (size_t)m->ent_cap * 2 * sizeof(float)));
     HIPCHK(hipMalloc(&m->d_enc_scratch, (size_t)m->ent_cap * kTileM * 64 * sizeof(float)));
@@ -163,7 +166,7 @@ int cfnerf_model_create(const cfnerf_cfg* cfg, cfnerf_model** out) {
 int cfnerf_model_destroy(cfnerf_model* m) {
     if (!m) return CFNERF_OK;
     hipDeviceSynchronize();
-    hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_descs); hipFree(m->d_ent_partials);
+    hipFree(m->d_packed); hipFree(m->d_packed16); hipFree(m->d_descs); hipFree(m->d_pack_table); hipFree(m->d_ent_partials);
     hipFree(m->d_enc_scratch);
     hipFree(m->d_eps);
     m->stash.release();
@@ -179,8 +182,7 @@ int cfnerf_model_set_params(cfnerf_model* m, const float* flat_params, cfnerf_st
     if (int rc = check_device(m)) return rc;
     m->flat = flat_params;
     // the split-bf16 copy is only refreshed while the opt-in mode is selected
-    HIPCHK(launch_pack(flat_params, m->d_packed, m->precision ? m->d_packed16 : nullptr, m->d_descs, (int)m->plan.descs.size(),
-                       m->plan.total_elems, (hipStream_t)s));
+    HIPCHK(launch_pack(flat_params, m->d_packed, m->precision ? m->d_packed16 : nullptr, m->d_pack_table, m->plan.total_elems, (hipStream_t)s));
     return CFNERF_OK;
 }
 
@@ -374,7 +376,7 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
     m->precision = mode;
     if (need_pack16) {      // bring the bf16 copy up to date with the current parameters (rare call: fully synchronous)
         HIPCHK(hipDeviceSynchronize());
-        HIPCHK(launch_pack(m->flat, m->d_packed, m->d_packed16, m->d_descs, (int)m->plan.descs.size(), m->plan.total_elems, nullptr));
+        HIPCHK(launch_pack(m->flat, m->d_packed, m->d_packed16, m->d_pack_table, m->plan.total_elems, nullptr));
         HIPCHK(hipDeviceSynchronize());
     }
     return CFNERF_OK;

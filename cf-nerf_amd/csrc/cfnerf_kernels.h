@@ -62,6 +62,7 @@ hipError_t launch_sample_pdf(const float* rays, const float* t_vals, const float
 hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hipStream_t st);
 hipError_t launch_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S, float* z, float* pts,
                                 hipStream_t st);
-hipError_t launch_pack(const float* flat, float* packed, void* packed16, const PackDesc* descs, int ndesc, uint32_t total, hipStream_t st);
+hipError_t launch_pack_index(const PackDesc* descs, int ndesc, uint32_t total, uint32_t* table /*[total][3]*/, hipStream_t st);      // once per model
+hipError_t launch_pack(const float* flat, float* packed, void* packed16, const uint32_t* table, uint32_t total, hipStream_t st);
 
 }  // namespace cfnerf

@@ -127,6 +127,7 @@ struct cfnerf_model {
     int precision = 0;                    // 0 = fp32 MFMA (default), 1 = bf16x3 split MFMA in the forward
     int flow_math = 0;                    // 0 = auto (libm below 16 latents, hardware transcendentals from there), 1 = libm, 2 = hardware
     cfnerf::PackDesc* d_descs = nullptr;
+    uint32_t* d_pack_table = nullptr;      // [plan.total_elems][3]: source, destination, bf16 destination of every copied element
     const float* flat = nullptr;          // caller-owned flat parameter buffer (last set_params)
     float* d_ent_partials = nullptr; int ent_cap = 0;
     float* d_enc_scratch = nullptr;       // [ent_cap, 64*64] forward scratch: one encoded tile per resident workgroup (8 MB, L2-resident)
