@@ -19,9 +19,18 @@ constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over
 // k-parts of the tail kernel for a batch: it runs ONE wave per SIMD, so a ray's latents are split over more waves only while all
 // waves still fit in one round (measured: a second round costs more than the shorter k-loops save); at most kTailParts, never more
 // than K / 2.  The workspace is carved for the CU count's upper bound (kMaxCu), the launch uses the device's own.
+// Round 4: the kernel fits 256 registers since it is built without the SLP vectoriser (cfnerf_tail.hip), so a SECOND wave per SIMD is
+// possible - it pays only while every part keeps >= 32 latents (K = 64 over 1024 rays: tail 0.256 -> 0.232 ms, backward-data +5 us for
+// the second partial g_theta it sums while loading; at 8 - 16 latents per part the k-loops run half empty and the extra partials cost
+// more than the tail gains: K = 32 over 512 rays at four parts +0.6 % on the step).
 inline int tail_parts(int64_t n_rays, int k, int n_cu) {
     int parts = 1;
-    while (parts < kTailParts && parts * 2 <= k && n_rays * parts * 2 <= (int64_t)n_cu * 4) parts *= 2;
+    while (parts < kTailParts && parts * 2 <= k) {
+        const bool one_round = n_rays * parts * 2 <= (int64_t)n_cu * 4;
+        const bool second_wave = n_rays * parts * 2 <= (int64_t)n_cu * 8 && k / (parts * 2) >= 32;
+        if (!one_round && !second_wave) break;
+        parts *= 2;
+    }
     return parts;
 }
 

@@ -141,7 +141,9 @@ __device__ __forceinline__ void store_gtheta_row(float* __restrict__ row, const 
     for (int q = 27; q < 32; ++q) gp[q] = zero;
 }
 
-__global__ __launch_bounds__(kThreads)
+// (two workgroups per CU = two waves per SIMD: tail_parts (cfnerf_model.h) counts on it for K >= 64; the kernel needs 255 registers
+// without the SLP vectoriser - tests/test_abi_cpu.py checks the built code object for spills)
+__global__ __launch_bounds__(kThreads, 2)
 void tail_bwd_kernel(const TailArgs A) {
 #pragma clang fp contract(fast)
     __shared__ float carry[kWaves][kMaxK];

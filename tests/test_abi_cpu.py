@@ -48,6 +48,18 @@ def test_dynamic_symbol_table_is_exactly_the_two_headers():
     assert exported == abi | hooks, {"undeclared": sorted(exported - abi - hooks)[:10], "missing": sorted((abi | hooks) - exported)}
 
 
+def test_tail_kernel_fits_two_waves_per_simd_without_spills():
+    """tail_parts() schedules a second wave per SIMD for K >= 64: the built tail kernel must fit 256 registers with nothing spilt
+    (it does since cfnerf_tail.hip is compiled without the SLP vectoriser; with it: 367 ArchVGPRs + 111 AccVGPRs)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_regs.py"), L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    row = [ln for ln in out.splitlines() if "tail_bwd_kernel" in ln]
+    assert len(row) == 1, out[-500:]
+    f = dict(re.findall(r"(\w+)=\s*(\d+)", row[0]))
+    assert int(f["vgpr"]) <= 256 and int(f["agpr"]) == 0 and int(f["vgpr_spill"]) == 0 and int(f["sgpr_spill"]) == 0 and int(f["scratch"]) == 0, row[0]
+
+
 @pytest.mark.parametrize("W,ha,hr", [(256, 32, 64), (64, 32, 64), (512, 64, 64), (128, 64, 64), (192, 32, 64), (320, 64, 32), (448, 32, 32), (256, 96, 128), (64, 128, 96)])
 def test_flat_layout_is_state_dict_order(W, ha, hr):
     F = 4 if W != 192 else 3                      # one case with --n_flows other than the default
