@@ -347,61 +347,54 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
         const int chunk = (int)(tile - ray * cpr);
         const int64_t p0 = ray * (int64_t)Sn + (int64_t)chunk * kTileM;
         const int rows_valid = min(kTileM, Sn - chunk * kTileM);
-        // ---- 0. g_theta tile -> act[:, 0:128).  ALL of a thread's eight pieces (and, per k-part, all eight of that part) are requested
-        //      before the first is consumed (round 4): as one plain loop the compiler kept it rolled - load, s_waitcnt vmcnt(0), ds_write,
-        //      next piece - i.e. eight serialised memory round trips at the top of every tile, sixteen with two k-parts (that, not
-        //      the bytes, was the ~40 us an extra k-part cost this kernel).
-        //      W <= 256 only: the wide kernel runs at 372 + 128 registers and one workgroup per CU, the 32 extra live registers cost it
-        //      +1.1 % (2.219 -> 2.245 ms at W = 512); it keeps the rolled loop.
-        if (W > 256) {
-            for (int idx = tid; idx < kTileM * (kThetaAll / 4); idx += kThreads) {
-                const int row = idx >> 5, q = idx & 31;
-                f32x4 v; v[0] = v[1] = v[2] = v[3] = 0.f;
-                if (row < rows_valid) {
-                    v = *reinterpret_cast<const f32x4*>(A.g_theta + (p0 + row) * kThetaAll + q * 4);
-                    if (A.g_parts > 1) {
-                        for (int part = 1; part < A.g_parts; ++part)
-                            v += *reinterpret_cast<const f32x4*>(A.g_theta + ((size_t)part * P + p0 + row) * kThetaAll + q * 4);
-                        *reinterpret_cast<f32x4*>(const_cast<float*>(A.g_theta) + (p0 + row) * kThetaAll + q * 4) = v;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD, LD, q * 4 + c, v[c]);
-            }
-        } else {
+        // ---- 0. g_theta tile -> act[:, 0:128).  A thread's eight 16-byte pieces are requested in BATCHES before the first of a batch is
+        //      consumed (round 4): as one plain loop the compiler kept it rolled - load, s_waitcnt vmcnt(0), ds_write, next piece - i.e.
+        //      eight serialised memory round trips at the top of every tile, sixteen with two k-parts (that, not the bytes, was the ~40 us
+        //      an extra k-part cost this kernel).  W <= 256: one batch of eight (two workgroups per CU: 27 more VGPRs are free).  The wide
+        //      kernels run at 372 + 128 registers and one workgroup per CU - all eight in flight cost them +1.1 % - and take batches of
+        //      kGthB pieces.
+        {
             constexpr int kGthN = kTileM * (kThetaAll / 4) / kThreads;
+#ifdef CFN_GTH_BATCH       // (A/B builds)
+            constexpr int kGthB = (W <= 256) ? kGthN : CFN_GTH_BATCH;
+#else
+            constexpr int kGthB = (W <= 256) ? kGthN : 1;
+#endif
             const float* const gth = A.g_theta;
             const int parts = A.g_parts;
-            f32x4 gv[kGthN];
 #pragma unroll
-            for (int i = 0; i < kGthN; ++i) {
-                const int idx = tid + i * kThreads, row = idx >> 5, q = idx & 31;
-                gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
-                if (row < rows_valid) gv[i] = *reinterpret_cast<const f32x4*>(gth + (p0 + row) * kThetaAll + q * 4);
-            }
-            if (parts > 1) {                                       // partial sums of the tail kernel's k-parts, fixed order;
-                for (int part = 1; part < parts; ++part) {         // the total goes back to part 0: the theta-head dW jobs read it
-                    f32x4 pv[kGthN];
+            for (int b0 = 0; b0 < kGthN; b0 += kGthB) {
+                f32x4 gv[kGthB];
 #pragma unroll
-                    for (int i = 0; i < kGthN; ++i) {
-                        const int idx = tid + i * kThreads, row = idx >> 5, q = idx & 31;
-                        pv[i][0] = pv[i][1] = pv[i][2] = pv[i][3] = 0.f;
-                        if (row < rows_valid) pv[i] = *reinterpret_cast<const f32x4*>(gth + ((size_t)part * P + p0 + row) * kThetaAll + q * 4);
+                for (int i = 0; i < kGthB; ++i) {
+                    const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
+                    gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
+                    if (row < rows_valid) gv[i] = *reinterpret_cast<const f32x4*>(gth + (p0 + row) * kThetaAll + q * 4);
+                }
+                if (parts > 1) {                                   // partial sums of the tail kernel's k-parts, fixed order;
+                    for (int part = 1; part < parts; ++part) {     // the total goes back to part 0: the theta-head dW jobs read it
+                        f32x4 pv[kGthB];
+#pragma unroll
+                        for (int i = 0; i < kGthB; ++i) {
+                            const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
+                            pv[i][0] = pv[i][1] = pv[i][2] = pv[i][3] = 0.f;
+                            if (row < rows_valid) pv[i] = *reinterpret_cast<const f32x4*>(gth + ((size_t)part * P + p0 + row) * kThetaAll + q * 4);
+                        }
+#pragma unroll
+                        for (int i = 0; i < kGthB; ++i) gv[i] += pv[i];
                     }
 #pragma unroll
-                    for (int i = 0; i < kGthN; ++i) gv[i] += pv[i];
+                    for (int i = 0; i < kGthB; ++i) {
+                        const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
+                        if (row < rows_valid) *reinterpret_cast<f32x4*>(const_cast<float*>(gth) + (p0 + row) * kThetaAll + q * 4) = gv[i];
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < kGthN; ++i) {
-                    const int idx = tid + i * kThreads, row = idx >> 5, q = idx & 31;
-                    if (row < rows_valid) *reinterpret_cast<f32x4*>(const_cast<float*>(gth) + (p0 + row) * kThetaAll + q * 4) = gv[i];
+                for (int i = 0; i < kGthB; ++i) {
+                    const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD, LD, q * 4 + c, gv[i][c]);
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < kGthN; ++i) {
-                const int idx = tid + i * kThreads, row = idx >> 5, q = idx & 31;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) act_store<PREC>(act + row * LD, LD, q * 4 + c, gv[i][c]);
             }
         }
         __syncthreads();
