@@ -58,8 +58,19 @@ def render_truth(sc, c2w, dev, n_quad=512):
     return ((alpha * T)[..., None] * col).sum(1).reshape(H, W, 3).float()
 
 
+_MADE = {}
+
+
 def make(dev="cuda", seed=7):
-    """(poses [20,3,4] cpu, images [20,H,W,3] cpu, i_train, i_test)"""
+    """(poses [20,3,4] cpu, images [20,H,W,3] cpu, i_train, i_test); rendered once per (device, seed) and process"""
+    key = (str(dev), int(seed))
+    if key not in _MADE:
+        _MADE[key] = _make(dev, seed)
+    poses, images, i_train, i_test = _MADE[key]
+    return poses.clone(), images.clone(), list(i_train), list(i_test)
+
+
+def _make(dev, seed):
     rng = np.random.default_rng(seed)
     sc = blobs(rng, dev)
     poses = [pose_spherical(th, -20.0 - 10.0 * (i % 3), 4.0) for i, th in enumerate(np.linspace(-60, 60, 20))]
