@@ -365,6 +365,7 @@ int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* ray
     if (N < 0 || S < 1 || K < 1) return fail(CFNERF_E_INVALID, "bad N/S/K");
     if (N == 0) return CFNERF_OK;
     if (!raw || !z_vals || !rays_d || !rgb_map || !disp_map || !depth_map) return fail(CFNERF_E_INVALID, "NULL argument");
+    if ((int64_t)S * K * 16 >= (1ll << 31)) return fail(CFNERF_E_UNSUPPORTED, "cfnerf_composite_fwd: S * K * 16 bytes per ray must stay below 2 GiB");
     HIPCHK(launch_composite(raw, z_vals, rays_d, N, S, K, white_bkgd, rgb_map, disp_map, depth_map, weights_opt, (hipStream_t)s));
     return CFNERF_OK;
 }

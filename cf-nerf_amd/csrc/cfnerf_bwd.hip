@@ -118,89 +118,158 @@ __global__ void loss_finalize_kernel(const float* __restrict__ entropy, float be
 // composite_bwd_kernel: adjoint of raw2outputs (RUN:411-454) as a stateless call.  One wave per ray, lane = sample; the forward
 // is recomputed with the forward kernels' own arithmetic (softplus / exp / wave product scan with a per-chunk carry), the carry
 // of every 64-sample chunk is parked in LDS, then the chunks are walked back to front exactly like the fused tail kernel.
+// Memory side (round 4, like composite_kernel in cfnerf_fwd.hip): KG latents at a time; a chunk's [64][KG] block of raw arrives by
+// LDS-DMA in fully coalesced 1-KB pieces (CompStage, cfnerf_device.h), d_raw is written INTO the block's slots and leaves by the
+// same pieces - rounds 1-3 read and wrote 16 bytes per lane at a stride of 16 K bytes, once per latent (0.7 TB/s at K = 32).
 //   d loss / d w_s = sum_c G_c c_s + Gd' z_s + Ga + Gw_s     with  Gd' = Gd + Gdisp d disp / d depth,
 //   Ga = Gdisp d disp / d acc - [white_bkgd] sum_c G_c       (disp = 1 / max(2e-10, depth / (acc + 1e-10) + 1e-10), RUN:448)
 constexpr int kCompMaxChunks = 64;            // S <= 4096
+template <int KG, bool FAST>
 __global__ __launch_bounds__(kThreads)
 void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t N, int S,
                           int K, int white_bkgd, const float* __restrict__ d_rgb, const float* __restrict__ d_disp,
                           const float* __restrict__ d_depth, const float* __restrict__ d_weights, float* __restrict__ d_raw) {
 #pragma clang fp contract(fast)      // (like the fused tail kernel: the two must agree to rounding, see tests/test_hip_unfused_seam.py)
-    __shared__ float carryT[kWaves][kCompMaxChunks];
+    using M = Num<FAST>;
+    using St = CompStage<KG>;
+    __shared__ __attribute__((aligned(16))) float stage_all[kWaves][St::kQuads * 4];
+    __shared__ float carryT[kWaves][KG][kCompMaxChunks];
     const int lane = lane_id_opaque(), wave = wave_id();
     const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
     if (ray >= N) return;
+    float* stage = stage_all[wave];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)stage);
     const float* d = rays_d + ray * 3;
     const float dnorm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     const float* zr = z_vals + ray * (int64_t)S;
+    const i32x4 rsrc = ds_rsrc(raw + ray * (int64_t)S * K * 4, S * K * 16);
+    float* drow = d_raw + ray * (int64_t)S * K * 4;
     const int nch = (S + 63) / 64;
-    for (int k = 0; k < K; ++k) {
-        // ---- forward sums of this latent (depth, acc) and the transmittance entering every chunk
-        float car = 1.f, ad = 0.f, aa = 0.f;
+    const bool vec_w = d_weights != nullptr && (K & 3) == 0;
+    unsigned voff[KG];
+#pragma unroll
+    for (int j = 0; j < KG; ++j) voff[j] = St::piece_voff(lane, j, K);
+    const int my_q0 = lane * KG, my_swz = St::swz(lane);
+    auto fetch = [&](int ch, int g0) { St::fetch(rsrc, lds0, voff, ch, g0, K); };
+    auto landed = [&]() { St::landed(); };
+    for (int g0 = 0; g0 < K; g0 += KG) {
+        // ---- forward sums of the group's latents (depth, acc) and the transmittance entering every chunk
+        float car[KG];
+        float accd = 0.f, acca = 0.f;                        // lane q: latent g0 + q
+#pragma unroll
+        for (int q = 0; q < KG; ++q) car[q] = 1.f;
         for (int ch = 0; ch < nch; ++ch) {
             const int s = ch * 64 + lane;
             const bool valid = s < S;
-            float zv = 0.f, alpha = 0.f;
+            fetch(ch, g0);
+            float zv = 0.f, dist = 0.f;
             if (valid) {
-                zv = zr[s];
-                const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
-                alpha = 1.f - expf(-softplus_f(raw[((ray * S + s) * (int64_t)K + k) * 4 + 3]) * (dz * dnorm));
-            }
-            float incl, excl;
-            comp_scan_mul((1.f - alpha) + 1e-10f, incl, excl);
-            if (lane == 0) carryT[wave][ch] = car;
-            const float wgt = alpha * (car * excl);
-            ad += comp_sum(wgt * zv);
-            aa += comp_sum(wgt);
-            car *= comp_last(incl);
-        }
-        const float G0 = d_rgb[ray * 3 * (int64_t)K + 0 * K + k], G1 = d_rgb[ray * 3 * (int64_t)K + 1 * K + k], G2 = d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
-        float Gd = (d_depth != nullptr) ? d_depth[ray * (int64_t)K + k] : 0.f;
-        float Ga = white_bkgd ? -(G0 + G1 + G2) : 0.f;
-        if (d_disp != nullptr) {
-            const float q = ad / (aa + 1e-10f) + 1e-10f;
-            if (q > 1e-10f + 1e-10f) {                                         // torch.max routes the gradient to the larger argument
-                const float gq = -d_disp[ray * (int64_t)K + k] / (q * q);
-                Gd += gq / (aa + 1e-10f);
-                Ga += gq * (-ad / ((aa + 1e-10f) * (aa + 1e-10f)));
-            }
-        }
-        // ---- back to front: suffix sums of g w as a reverse wave scan + a carry (see tail_bwd_kernel)
-        float sufcar = 0.f;
-        for (int ch = nch - 1; ch >= 0; --ch) {
-            const int s = ch * 64 + lane;
-            const bool valid = s < S;
-            const int64_t idx = (ray * S + (valid ? s : 0)) * (int64_t)K + k;
-            f32x4 rv; rv[0] = rv[1] = rv[2] = rv[3] = 0.f;
-            float zv = 0.f, dist = 0.f, alpha = 0.f;
-            if (valid) {
-                rv = *reinterpret_cast<const f32x4*>(raw + idx * 4);
                 zv = zr[s];
                 const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
                 dist = dz * dnorm;
-                alpha = 1.f - expf(-softplus_f(rv[3]) * dist);
             }
-            const float xk = (1.f - alpha) + 1e-10f;
-            float incl_m, excl_m;
-            comp_scan_mul(xk, incl_m, excl_m);
-            const float Tt = carryT[wave][ch] * excl_m;
-            const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
-            const float w = alpha * Tt;
-            float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
-            g += Ga;
-            if (d_weights != nullptr && valid) g += d_weights[idx];
-            const float gw = valid ? g * w : 0.f;
-            float excl, tot;
-            comp_suffix(gw, excl, tot);
-            const float suffix = excl + sufcar;
-            sufcar += tot;
-            const float dalpha = g * Tt - suffix * t_rcp(xk);
-            const float sg = t_sigmoid(rv[3]);                                 // softplus'
+            landed();
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                if (g0 + q < K) {
+                    const float r3 = stage[(my_q0 + (q ^ my_swz)) * 4 + 3];
+                    const float alpha = valid ? 1.f - M::exp(-M::softplus(r3) * dist) : 0.f;
+                    float incl, excl;
+                    comp_scan_mul((1.f - alpha) + 1e-10f, incl, excl);
+                    if (lane == 0) carryT[wave][q][ch] = car[q];
+                    const float wgt = alpha * (car[q] * excl);
+                    const float sd = comp_sum(wgt * zv), sa = comp_sum(wgt);
+                    if (lane == q) { accd += sd; acca += sa; }
+                    car[q] *= comp_last(incl);
+                }
+            }
+        }
+        // ---- cotangents of the group's latents, lane q: latent g0 + q
+        float G0v = 0.f, G1v = 0.f, G2v = 0.f, Gdv = 0.f, Gav = 0.f;
+        {
+            const int k = g0 + lane;
+            if (lane < KG && k < K) {
+                G0v = d_rgb[ray * 3 * (int64_t)K + 0 * K + k]; G1v = d_rgb[ray * 3 * (int64_t)K + 1 * K + k]; G2v = d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
+                Gdv = (d_depth != nullptr) ? d_depth[ray * (int64_t)K + k] : 0.f;
+                Gav = white_bkgd ? -(G0v + G1v + G2v) : 0.f;
+                if (d_disp != nullptr) {
+                    const float qq = accd / (acca + 1e-10f) + 1e-10f;
+                    if (qq > 1e-10f + 1e-10f) {                                    // torch.max routes the gradient to the larger argument
+                        const float gq = -d_disp[ray * (int64_t)K + k] / (qq * qq);
+                        Gdv += gq / (acca + 1e-10f);
+                        Gav += gq * (-accd / ((acca + 1e-10f) * (acca + 1e-10f)));
+                    }
+                }
+            }
+        }
+        // ---- back to front: suffix sums of g w as a reverse wave scan + a carry (see tail_bwd_kernel)
+        float sufcar[KG];
+#pragma unroll
+        for (int q = 0; q < KG; ++q) sufcar[q] = 0.f;
+        for (int ch = nch - 1; ch >= 0; --ch) {
+            const int s = ch * 64 + lane;
+            const bool valid = s < S;
+            fetch(ch, g0);
+            float zv = 0.f, dist = 0.f;
+            float dwv[KG];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) dwv[q] = 0.f;
             if (valid) {
-                f32x4 o;
-                o[0] = G0 * w * c0 * (1.f - c0); o[1] = G1 * w * c1 * (1.f - c1); o[2] = G2 * w * c2 * (1.f - c2);
-                o[3] = dalpha * (1.f - alpha) * dist * sg;
-                *reinterpret_cast<f32x4*>(d_raw + idx * 4) = o;
+                zv = zr[s];
+                const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
+                dist = dz * dnorm;
+                if (d_weights != nullptr) {
+                    const float* wrow = d_weights + (ray * S + s) * (int64_t)K + g0;
+                    if (vec_w) {
+#pragma unroll
+                        for (int q = 0; q < KG; q += 4)
+                            if (g0 + q < K) { const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + q); dwv[q] = v[0]; dwv[q + 1] = v[1]; dwv[q + 2] = v[2]; dwv[q + 3] = v[3]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < KG; ++q)
+                            if (g0 + q < K) dwv[q] = wrow[q];
+                    }
+                }
+            }
+            landed();
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                if (g0 + q < K) {
+                    float* slot = stage + (my_q0 + (q ^ my_swz)) * 4;
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(slot);
+                    const float G0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G0v), q)), G1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G1v), q)),
+                                G2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G2v), q)), Gd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Gdv), q)),
+                                Ga = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Gav), q));
+                    const float alpha = valid ? 1.f - M::exp(-M::softplus(rv[3]) * dist) : 0.f;
+                    const float xk = (1.f - alpha) + 1e-10f;
+                    float incl_m, excl_m;
+                    comp_scan_mul(xk, incl_m, excl_m);
+                    const float Tt = carryT[wave][q][ch] * excl_m;
+                    const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
+                    const float w = alpha * Tt;
+                    float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
+                    g += Ga;
+                    g += dwv[q];
+                    const float gw = valid ? g * w : 0.f;
+                    float excl, tot;
+                    comp_suffix(gw, excl, tot);
+                    const float suffix = excl + sufcar[q];
+                    sufcar[q] += tot;
+                    const float dalpha = g * Tt - suffix * t_rcp(xk);
+                    const float sg = t_sigmoid(rv[3]);                                 // softplus'
+                    f32x4 o;
+                    o[0] = G0 * w * c0 * (1.f - c0); o[1] = G1 * w * c1 * (1.f - c1); o[2] = G2 * w * c2 * (1.f - c2);
+                    o[3] = dalpha * (1.f - alpha) * dist * sg;
+                    *reinterpret_cast<f32x4*>(slot) = o;                               // in place: the block leaves the way it came
+                }
+            }
+            wave_lds_turn();
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const int p = j * 64 + lane, sl = p / KG, kk = (p % KG) ^ St::swz(sl);
+                const int sj = ch * 64 + sl, k = g0 + kk;
+                if (sj < S && k < K)
+                    *reinterpret_cast<f32x4*>(drow + ((int64_t)sj * K + k) * 4) = *reinterpret_cast<const f32x4*>(stage + p * 4);
             }
         }
     }
@@ -555,25 +624,7 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-// ---- LDS-DMA helpers (used by the fp32 big-tile loader and the small-job kernel)
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ i32x4 ds_rsrc(const float* base, int bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000;
-    return r;
-}
-// one 1-KB LDS-DMA piece: lane l's 16 bytes at (descriptor base + soff + voff) land at lds_addr + 16 l.  M0 is written in the
-// statement that reads it and restored (it is compiler-reserved).
-__device__ __forceinline__ void ds_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
+// ---- LDS-DMA helpers: ds_rsrc / ds_dma16 live in cfnerf_device.h (the standalone composite kernels use them too)
 __device__ __forceinline__ void ds_wait_stage(int n_w) {   // at most n_w of this wave's pieces still in flight (wave-uniform n_w)
     if (n_w == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (n_w == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1458,8 +1509,13 @@ int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* ray
     if (S > 64 * kCompMaxChunks) return bfail(CFNERF_E_UNSUPPORTED, "cfnerf_composite_bwd supports S <= %d", 64 * kCompMaxChunks);
     if (N == 0) return CFNERF_OK;
     if (!raw || !z_vals || !rays_d || !d_rgb_map || !d_raw) return bfail(CFNERF_E_INVALID, "NULL argument");
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, (hipStream_t)s, raw, z_vals, rays_d, N, S,
-                       K, white_bkgd, d_rgb_map, d_disp_map, d_depth_map, d_weights, d_raw);
+    if ((int64_t)S * K * 16 >= (1ll << 31)) return bfail(CFNERF_E_UNSUPPORTED, "cfnerf_composite_bwd: S * K * 16 bytes per ray must stay below 2 GiB");
+#define CFN_COMPB(KG, FAST) hipLaunchKernelGGL((composite_bwd_kernel<KG, FAST>), dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, \
+                       (hipStream_t)s, raw, z_vals, rays_d, N, S, K, white_bkgd, d_rgb_map, d_disp_map, d_depth_map, d_weights, d_raw)
+    if (K <= 4) CFN_COMPB(4, false);                // (the same split as launch_composite: forward and adjoint share their arithmetic)
+    else if (K < kFastFlowsK) CFN_COMPB(8, false);
+    else CFN_COMPB(8, true);
+#undef CFN_COMPB
     BHIP(hipGetLastError());
     return CFNERF_OK;
 }

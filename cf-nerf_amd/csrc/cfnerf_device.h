@@ -728,4 +728,57 @@ __device__ __forceinline__ void flows_fwd(const float (&th)[84], float (&z)[3], 
     }
 }
 
+// ---- LDS-DMA helpers (the fp32 big-tile loader, the small-job kernel, the standalone composite kernels)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 ds_rsrc(const float* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// one 1-KB LDS-DMA piece: lane l's 16 bytes at (descriptor base + soff + voff) land at lds_addr + 16 l.  M0 is written in the
+// statement that reads it and restored (it is compiler-reserved).
+__device__ __forceinline__ void ds_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// ---- a wave's private LDS block as a turntable (standalone composite kernels: cfnerf_fwd.hip / cfnerf_bwd.hip)
+// A wave's own LDS queue is in order; this only keeps the COMPILER from moving LDS accesses across the point where lanes exchange data.
+__device__ __forceinline__ void wave_lds_turn() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// The [64 samples][KG latents] block of quads (16 bytes = one (sample, latent) entry of raw [N,S,K,4]) of a 64-sample chunk, filled by
+// KG LDS-DMA pieces: piece j, lane l lands at quad position p = 64 j + l.  Position p = sl * KG + c holds latent kk = c ^ swz(sl) of
+// sample sl: the KG lanes of a sample still cover its one 16 KG-byte segment of global memory (every piece is 1 KB of full cache lines
+// when K is a multiple of KG), and the transposed read - lane = sample, one latent - touches 16 different bank quads per 16 lanes.
+template <int KG> struct CompStage {
+    static_assert(KG == 4 || KG == 8, "a sample's segment is 64 or 128 bytes");
+    static constexpr int kQuads = 64 * KG;
+    static __device__ __forceinline__ int swz(int sl) { return (sl / (16 / KG)) & (KG - 1); }
+    // this lane's byte offset (inside the chunk's rows of the ray, group 0) of the quad it moves in piece j
+    static __device__ __forceinline__ unsigned piece_voff(int lane, int j, int K) {
+        const int p = j * 64 + lane, sl = p / KG, kk = (p % KG) ^ swz(sl);
+        return (unsigned)((sl * K + kk) * 16);
+    }
+    static __device__ __forceinline__ void fetch(i32x4 rsrc, unsigned lds0, const unsigned (&voff)[KG], int ch, int g0, int K) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous block's LDS reads have their data
+        wave_lds_turn();
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((ch * 64 * K + g0) * 16);
+#pragma unroll
+        for (int j = 0; j < KG; ++j) ds_dma16(rsrc, lds0 + j * 1024, voff[j], soff);
+    }
+    static __device__ __forceinline__ void landed() {            // (hipcc does not count asm memory operations: explicit wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_turn();
+    }
+};
+
 }  // namespace cfnerf

@@ -710,52 +710,112 @@ __global__ void entropy_finalize_kernel(const float* partials, int n_part, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// standalone composite (raw2outputs RUN:411-454): one wave per ray, lane = sample, loop over k.
-// HBM-bound: reads 16*S*K + 4*S + 12 bytes per ray, writes 20*K (+4*S*K for weights).
+// standalone composite (raw2outputs RUN:411-454): one wave per ray, lane = sample.
+// Reads 16*S*K + 4*S + 12 bytes per ray, writes 20*K (+4*S*K for weights).  `raw [N,S,K,4]` has the latent index inside the sample
+// index, so "lane = sample, one k at a time" (rounds 1-3) read 16 bytes per lane at a stride of 16 K bytes and came back K times for
+// the rest of every cache line (0.9 TB/s at K = 32).  Now a wave takes KG latents at a time: the [64 samples][KG latents] block of a
+// chunk arrives by LDS-DMA as KG fully coalesced 1-KB pieces into the wave's own LDS block (CompStage, cfnerf_device.h: no staging
+// registers, conflict-free transposed reads) and the KG latents are walked out of LDS with the arithmetic of rounds 1-3 (= the fused
+// kernel's composite) operation for operation; a latent's carry and sums wait in LDS between the chunks (entry = lane), so the maps
+// leave as one store per output.
+// Transcendentals like the fused kernels: libm below kFastFlowsK latents (there the kernel is bound by libm's instruction count,
+// not by memory), the hardware forms from there on (Num<FAST>).
+constexpr int kCompKB = 64;       // latents of one pass over a ray's chunks (their carries and sums wait in LDS, entry = lane)
+template <int KG, bool FAST>
 __global__ __launch_bounds__(kThreads)
 void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d,
                       int64_t N, int S, int K, int white_bkgd, float* rgb_map, float* disp_map, float* depth_map,
                       float* weights) {
+    using M = Num<FAST>;
+    using St = CompStage<KG>;
+    __shared__ __attribute__((aligned(16))) float stage_all[kWaves][St::kQuads * 4];
+    __shared__ float sums_all[kWaves][6][kCompKB];           // [0] transmittance entering the next chunk, [1..5] rgb / depth / acc sums
     const int lane = lane_id();
-    const int64_t ray = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    if (ray >= N) return;
+    const int wave = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+    if (ray >= N) return;                                    // (no workgroup barrier below: a wave leaves alone)
+    float* stage = stage_all[wave];
+    float (*sums)[kCompKB] = sums_all[wave];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)stage);
     const float* d = rays_d + ray * 3;
     const float dnorm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     const float* zr = z_vals + ray * (int64_t)S;
+    const i32x4 rsrc = ds_rsrc(raw + ray * (int64_t)S * K * 4, S * K * 16);      // samples past S arrive as zeros (bounds check)
     const int nch = (S + 63) / 64;
-    for (int k = 0; k < K; ++k) {
-        float car = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, aa = 0.f;
+    const bool vec_w = weights != nullptr && (K & 3) == 0;   // a lane's KG weights of a sample as 16-byte stores
+    unsigned voff[KG];
+#pragma unroll
+    for (int j = 0; j < KG; ++j) voff[j] = St::piece_voff(lane, j, K);
+    const int my_q0 = lane * KG, my_swz = St::swz(lane);
+    // Chunk-major: all latents of a chunk before the next chunk, so that raw streams through once front to back and the KG-float
+    // pieces a group adds to a sample's row of `weights` complete their cache lines while these are still in L2.
+    for (int kb = 0; kb < K; kb += kCompKB) {
+        const int kn = min(K - kb, kCompKB);
+        sums[0][lane] = 1.f;
+#pragma unroll
+        for (int c = 1; c < 6; ++c) sums[c][lane] = 0.f;
         for (int ch = 0; ch < nch; ++ch) {
             const int s = ch * 64 + lane;
             const bool valid = s < S;
             float zv = 0.f, dist = 0.f;
-            f32x4 rv; rv[0] = rv[1] = rv[2] = rv[3] = 0.f;
             if (valid) {
                 zv = zr[s];
                 const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
                 dist = dz * dnorm;
-                rv = *reinterpret_cast<const f32x4*>(raw + ((ray * S + s) * (int64_t)K + k) * 4);
             }
-            const float alpha = valid ? 1.f - expf(-softplus_f(rv[3]) * dist) : 0.f;
-            const float xk = (1.f - alpha) + 1e-10f;
-            float incl, excl;
-            comp_scan_mul(xk, incl, excl);
-            const float wgt = alpha * (car * excl);
-            if (weights != nullptr && valid) weights[(ray * S + s) * (int64_t)K + k] = wgt;
-            a0 += comp_sum(wgt * sigmoid_f(rv[0]));
-            a1 += comp_sum(wgt * sigmoid_f(rv[1]));
-            a2 += comp_sum(wgt * sigmoid_f(rv[2]));
-            ad += comp_sum(wgt * zv);
-            aa += comp_sum(wgt);
-            car *= comp_last(incl);
+            for (int gi = 0; gi < kn; gi += KG) {
+                const int g0 = kb + gi;
+                St::fetch(rsrc, lds0, voff, ch, g0, K);
+                // lane q < KG: latent g0 + q
+                const int slot = gi + (lane < KG ? lane : 0);
+                float carv = sums[0][slot], acc0 = sums[1][slot], acc1 = sums[2][slot], acc2 = sums[3][slot], accd = sums[4][slot], acca = sums[5][slot];
+                St::landed();
+                float wv[KG];
+#pragma unroll
+                for (int q = 0; q < KG; ++q) {
+                    wv[q] = 0.f;
+                    if (gi + q < kn) {                       // (uniform)
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(stage + (my_q0 + (q ^ my_swz)) * 4);
+                        const float car = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carv), q));
+                        const float alpha = valid ? 1.f - M::exp(-M::softplus(rv[3]) * dist) : 0.f;
+                        const float xk = (1.f - alpha) + 1e-10f;
+                        float incl, excl;
+                        comp_scan_mul(xk, incl, excl);
+                        const float wgt = alpha * (car * excl);
+                        wv[q] = wgt;
+                        const float s0 = comp_sum(wgt * M::sigmoid(rv[0])), s1 = comp_sum(wgt * M::sigmoid(rv[1])), s2 = comp_sum(wgt * M::sigmoid(rv[2]));
+                        const float sd = comp_sum(wgt * zv), sa = comp_sum(wgt);
+                        const float carn = car * comp_last(incl);
+                        if (lane == q) { acc0 += s0; acc1 += s1; acc2 += s2; accd += sd; acca += sa; carv = carn; }   // (chunk by chunk like the fused kernel)
+                    }
+                }
+                if (lane < KG) { sums[0][slot] = carv; sums[1][slot] = acc0; sums[2][slot] = acc1; sums[3][slot] = acc2; sums[4][slot] = accd; sums[5][slot] = acca; }
+                if (weights != nullptr && valid) {
+                    float* wrow = weights + (ray * S + s) * (int64_t)K + g0;
+                    if (vec_w) {
+#pragma unroll
+                        for (int q = 0; q < KG; q += 4)
+                            if (gi + q < kn) { f32x4 o; o[0] = wv[q]; o[1] = wv[q + 1]; o[2] = wv[q + 2]; o[3] = wv[q + 3]; *reinterpret_cast<f32x4*>(wrow + q) = o; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < KG; ++q)
+                            if (gi + q < kn) wrow[q] = wv[q];
+                    }
+                }
+            }
         }
-        if (lane == 0) {
-            if (white_bkgd) { a0 = a0 + (1.f - aa); a1 = a1 + (1.f - aa); a2 = a2 + (1.f - aa); }
+        wave_lds_turn();
+        if (lane < kn) {                                     // lane l: latent kb + l
+            const int k = kb + lane;
+            float r0 = sums[1][lane], r1 = sums[2][lane], r2 = sums[3][lane];
+            const float rd = sums[4][lane], ra = sums[5][lane];
+            if (white_bkgd) { r0 = r0 + (1.f - ra); r1 = r1 + (1.f - ra); r2 = r2 + (1.f - ra); }
             float* o = rgb_map + ray * 3 * (int64_t)K;
-            o[0 * K + k] = a0; o[1 * K + k] = a1; o[2 * K + k] = a2;
-            disp_map[ray * (int64_t)K + k] = 1.f / fmaxf(1e-10f + 1e-10f, ad / (aa + 1e-10f) + 1e-10f);
-            depth_map[ray * (int64_t)K + k] = ad;
+            o[0 * K + k] = r0; o[1 * K + k] = r1; o[2 * K + k] = r2;
+            disp_map[ray * (int64_t)K + k] = 1.f / fmaxf(1e-10f + 1e-10f, rd / (ra + 1e-10f) + 1e-10f);
+            depth_map[ray * (int64_t)K + k] = rd;
         }
+        wave_lds_turn();
     }
 }
 
@@ -822,12 +882,24 @@ hipError_t launch_ndc_rays(int H, int Wd, float focal, float nearv, const float*
 
 // ---------------------------------------------------------------------------------------------
 // standalone positional encoding (HLP:21-69) and ray sampling (RUN:510-534): the unfused boundary functions
-__global__ void embed_kernel(const float* __restrict__ x, int64_t P, int nch, float* __restrict__ out) {
+// One thread per (point, frequency, coordinate): ONE sincosf (the libm routine of the fused kernel's encode_tile: fused and unfused
+// encodings are bit-identical) gives the sin and the cos channel of that argument - rounds 1-3 ran one thread per output channel, i.e.
+// the routine twice per argument, and the kernel is bound by its ~100 instructions, not by the 264 bytes per point it moves.
+// Unit u of a point: u < 3 the identity channels, then u = 3 (f + 1) + d  ->  channels 3 + 6 f + d (sin) and 3 + 6 f + 3 + d (cos)  (HLP:42-51).
+__global__ void embed_kernel(const float* __restrict__ x, int64_t P, int multires, float* __restrict__ out) {
+    const int units = 3 * (multires + 1), nch = 3 + 6 * multires;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P * nch) return;
-    const int64_t p = idx / nch;
-    const int c = (int)(idx - p * nch);
-    out[idx] = enc_channel(x + p * 3, c);
+    if (idx >= P * units) return;
+    const int64_t p = idx / units;
+    const int u = (int)(idx - p * units);
+    const int f = u / 3 - 1, d = u - 3 * (f + 1);
+    const float v = x[p * 3 + d];
+    float* o = out + p * nch;
+    if (f < 0) { o[d] = v; return; }
+    float sv, cv;
+    sincosf(v * (float)(1 << f), &sv, &cv);                   // 2^f * v is exact in fp32
+    o[3 + 6 * f + d] = sv;
+    o[3 + 6 * f + 3 + d] = cv;
 }
 
 __global__ void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ t_vals, const float* __restrict__ t_rand,
@@ -853,9 +925,8 @@ __global__ void sample_points_kernel(const float* __restrict__ rays, const float
 }
 
 hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hipStream_t st) {
-    const int nch = 3 + 6 * multires;
-    const int64_t total = P * nch;
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, P, nch, out);
+    const int64_t total = P * 3 * (multires + 1);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, P, multires, out);
     return hipGetLastError();
 }
 
@@ -1070,7 +1141,11 @@ hipError_t launch_entropy_finalize(const float* partials, int n_part, const floa
 hipError_t launch_composite(const float* raw, const float* z, const float* d, int64_t N, int S, int K, int wb,
                             float* rgb, float* disp, float* depth, float* weights, hipStream_t st) {
     const int grid = (int)((N + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL(composite_kernel, dim3(grid), dim3(kThreads), 0, st, raw, z, d, N, S, K, wb, rgb, disp, depth, weights);
+#define CFN_COMP(KG, FAST) hipLaunchKernelGGL((composite_kernel<KG, FAST>), dim3(grid), dim3(kThreads), 0, st, raw, z, d, N, S, K, wb, rgb, disp, depth, weights)
+    if (K <= 4) CFN_COMP(4, false);                 // (a group of 4 latents = the whole 64-byte row of a sample at the headline K = 4)
+    else if (K < kFastFlowsK) CFN_COMP(8, false);
+    else CFN_COMP(8, true);
+#undef CFN_COMP
     return hipGetLastError();
 }
 

@@ -127,7 +127,8 @@ def test_composite_vs_reference_golden(golden, wb):
     close(disp, g[f"disp_{s}"], atol=ATOL_DISP, rtol=1e-3, what="disp")
 
 
-@pytest.mark.parametrize("N,S,K", [(5, 128, 4), (3, 70, 3), (2, 2, 1), (7, 200, 32), (1, 64, 5)])
+@pytest.mark.parametrize("N,S,K", [(5, 128, 4), (3, 70, 3), (2, 2, 1), (7, 200, 32), (1, 64, 5), (6, 129, 8), (3, 65, 13), (2, 300, 17), (5, 128, 64),
+                                   (2, 63, 128), (9, 2, 4), (1, 1000, 2)])
 def test_composite_vs_oracle_ragged(N, S, K):
     g = torch.Generator().manual_seed(N * 1000 + S + K)
     raw = torch.randn(N, S, K, 4, generator=g) * 3

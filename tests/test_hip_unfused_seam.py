@@ -20,7 +20,8 @@ def _rel_to_max(a, b):
 
 
 # ---------------------------------------------------------------- raw2outputs backward (RUN:411-454)
-@pytest.mark.parametrize("N,S,K,wb", [(6, 128, 4, False), (5, 128, 3, True), (4, 70, 2, False), (3, 200, 5, True), (2, 2, 1, False)])
+@pytest.mark.parametrize("N,S,K,wb", [(6, 128, 4, False), (5, 128, 3, True), (4, 70, 2, False), (3, 200, 5, True), (2, 2, 1, False),
+                                      (3, 129, 8, True), (2, 65, 13, False), (3, 200, 16, True), (2, 130, 33, False), (2, 128, 64, True)])
 def test_composite_backward_vs_oracle_autograd(N, S, K, wb):
     """every output of raw2outputs is differentiable with respect to raw: rgb_map, disp_map, weights, depth_map - incl. an
     opaque and an empty ray, ragged sample counts, the white-background branch"""
