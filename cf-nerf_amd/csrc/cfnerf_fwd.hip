@@ -791,6 +791,9 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
                 }
                 if (lane < KG) { sums[0][slot] = carv; sums[1][slot] = acc0; sums[2][slot] = acc1; sums[3][slot] = acc2; sums[4][slot] = accd; sums[5][slot] = acca; }
                 if (weights != nullptr && valid) {
+                    // (K > 4: 32-byte pieces at a pitch of 4 K bytes.  The same bytes as one contiguous 2-KB block per chunk and group -
+                    //  a timing-only build, wrong layout - took 289 instead of 414 us at K = 32: that is what the pieces cost; gathering
+                    //  four groups per sample for full 128-byte lines needs 8 KB more LDS per wave = half the resident waves. Not built.)
                     float* wrow = weights + (ray * S + s) * (int64_t)K + g0;
                     if (vec_w) {
 #pragma unroll
@@ -902,25 +905,56 @@ __global__ void embed_kernel(const float* __restrict__ x, int64_t P, int multire
     o[3 + 6 * f + 3 + d] = cv;
 }
 
-__global__ void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ t_vals, const float* __restrict__ t_rand,
-                                     int flags, int64_t N, int S, float* __restrict__ z_out, float* __restrict__ pts) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * S) return;
-    const int64_t n = idx / S;
-    const int s = (int)(idx - n * S);
-    const float* r = rays + n * 11;
-    const float nearv = r[6], farv = r[7];
+// One wave per ray, lane = sample, 64-sample chunks: no per-thread 64-bit division, the ray's 8 numbers are
+// scalar loads, t_rand and z move as coalesced rows, and a chunk's 768 bytes of `pts` leave as three coalesced stores - element f of
+// the block is coordinate f % 3 of sample f / 3, whose depth comes from that sample's lane through the wave's LDS row (same
+// `o + d * z`, RUN:534).  (Rounds 1-3: one thread per sample, three 4-byte stores at a stride of 12 bytes.)
+__global__ __launch_bounds__(kThreads)
+void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ t_vals, const float* __restrict__ t_rand,
+                          int flags, int64_t N, int S, float* __restrict__ z_out, float* __restrict__ pts) {
+    __shared__ float zs_all[kWaves][64];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* zs = zs_all[wave];
+    const int nch = (S + 63) / 64;
     const bool lind = (flags & CFNERF_F_LINDISP) != 0;
-    const float zc = zlin_f(t_vals[s], nearv, farv, lind);
-    float zv = zc;
-    if (t_rand != nullptr) {
-        const float upper = (s == S - 1) ? zc : 0.5f * (zlin_f(t_vals[s + 1], nearv, farv, lind) + zc);
-        const float lower = (s == 0) ? zc : 0.5f * (zc + zlin_f(t_vals[s - 1], nearv, farv, lind));
-        zv = lower + (upper - lower) * t_rand[idx];
-    }
-    z_out[idx] = zv;
-    if (pts != nullptr) {
-        pts[idx * 3 + 0] = r[0] + r[3] * zv; pts[idx * 3 + 1] = r[1] + r[4] * zv; pts[idx * 3 + 2] = r[2] + r[5] * zv;   // RUN:534
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };   // wave-uniform value in an SGPR
+    for (int64_t n = (int64_t)blockIdx.x * kWaves + wave; n < N; n += (int64_t)gridDim.x * kWaves) {     // (no workgroup barrier below)
+        const float* r = rays + n * 11;
+        const float o0 = uni(r[0]), o1 = uni(r[1]), o2 = uni(r[2]), d0 = uni(r[3]), d1 = uni(r[4]), d2 = uni(r[5]);
+        const float nearv = uni(r[6]), farv = uni(r[7]);
+        for (int ch = 0; ch < nch; ++ch) {
+            const int s = ch * 64 + lane;
+            const bool valid = s < S;
+            // every operand requested before the first is used (clamped neighbours: the selects below take what rounds 1-3 computed)
+            const int sc = min(s, S - 1);
+            const float tc = t_vals[sc], tp = t_vals[min(sc + 1, S - 1)], tm = t_vals[max(sc - 1, 0)];
+            const float tr = (t_rand != nullptr) ? t_rand[n * S + sc] : 0.f;
+            const float zc = zlin_f(tc, nearv, farv, lind);
+            float zv = zc;
+            if (t_rand != nullptr) {
+                const float upper = (sc == S - 1) ? zc : 0.5f * (zlin_f(tp, nearv, farv, lind) + zc);
+                const float lower = (sc == 0) ? zc : 0.5f * (zc + zlin_f(tm, nearv, farv, lind));
+                zv = lower + (upper - lower) * tr;
+            }
+            if (valid) z_out[n * S + s] = zv;
+            if (pts != nullptr) {
+                wave_lds_turn();
+                zs[lane] = zv;
+                wave_lds_turn();
+                float* prow = pts + (n * S + (int64_t)ch * 64) * 3;
+                float pv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int f = c * 64 + lane, sl = f / 3, comp = f - 3 * sl;
+                    const float o = comp == 0 ? o0 : (comp == 1 ? o1 : o2), dd = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
+                    pv[c] = o + dd * zs[sl];                                                                      // RUN:534
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)                  // (values first, stores after: a store's data register is not reused under it)
+                    if (ch * 64 + (c * 64 + lane) / 3 < S) prow[c * 64 + lane] = pv[c];
+            }
+        }
     }
 }
 
@@ -932,8 +966,9 @@ hipError_t launch_embed(const float* x, int64_t P, int multires, float* out, hip
 
 hipError_t launch_sample_points(const float* rays, const float* t_vals, const float* t_rand, int flags, int64_t N, int S, float* z, float* pts,
                                 hipStream_t st) {
-    const int64_t total = N * S;
-    hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rays, t_vals, t_rand, flags, N, S, z, pts);
+    const int64_t groups = (N + kWaves - 1) / kWaves;
+    const unsigned grid = (unsigned)std::min<int64_t>(groups, 1 << 30);           // (one ray per wave; the loop only covers N beyond that)
+    hipLaunchKernelGGL(sample_points_kernel, dim3(grid), dim3(kThreads), 0, st, rays, t_vals, t_rand, flags, N, S, z, pts);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ lib = L.lib()
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def ev_ms(fn, n=30, warm=10):
+def ev_ms(fn, n=30, warm=40):                        # (the first launches after an allocation run at ramping clocks)
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,6 +34,12 @@ def line(name, shape, nbytes, ms):
 def main():
     dev = "cuda"
     S = 128
+    # what this box's memory system gives a trivial kernel (context for the write-heavy stages below): torch's fill and copy over 1 GiB
+    a, b = torch.empty(1 << 28, device=dev), torch.empty(1 << 28, device=dev)
+    line("(context) torch fill_, 1 GiB written", "", a.numel() * 4, ev_ms(lambda: a.fill_(1.0)))
+    line("(context) torch copy_, 1 + 1 GiB", "", 2 * a.numel() * 4, ev_ms(lambda: b.copy_(a)))
+    line("(context) torch sum, 1 GiB read", "", a.numel() * 4, ev_ms(lambda: a.sum()))
+    del a, b
     print(f"{'kernel':34s} {'shape':28s} {'algorithmic':>12s}  {'launch':>12s}  {'achieved':>12s}")
     for (N, K) in ((65536, 4), (16384, 32), (8192, 64)):
         raw = torch.randn(N, S, K, 4, device=dev)
@@ -63,6 +69,13 @@ def main():
         out = torch.empty(P, 3 + 6 * mr, device=dev)
         ms = ev_ms(lambda: L.check(lib.cfnerf_embed(L.ptr(x), P, mr, L.ptr(out), L.stream()), "embed"))
         line("embed_kernel", f"P={P} multires={mr}", P * (12 + 4 * (3 + 6 * mr)), ms)
+    # stratified sampling + points (RUN:510-534): 44 B per ray and 4 B of t_rand per sample in, 4 (z) + 12 (pts) B per sample out
+    N, S = 1 << 18, 128
+    rays = torch.randn(N, 11, device=dev); rays[:, 6] = 0.0; rays[:, 7] = 1.0
+    t_vals = torch.linspace(0, 1, S, device=dev); t_rand = torch.rand(N, S, device=dev)
+    z, pts = torch.empty(N, S, device=dev), torch.empty(N, S, 3, device=dev)
+    ms = ev_ms(lambda: L.check(lib.cfnerf_sample_points(L.ptr(rays), L.ptr(t_vals), L.ptr(t_rand), 0, N, S, L.ptr(z), L.ptr(pts), L.stream()), "sample"))
+    line("sample_points_kernel", f"N={N} S={S}", N * (44 + S * 20), ms)
 
 
 if __name__ == "__main__":
