@@ -274,8 +274,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         q.n_tiles = N * (int64_t)((S + kTileM - 1) / kTileM);
         a.n_tiles = q.n_tiles;
         a.raw = q.raw;                       // the backward reads the model's OWN copy: the caller may drop its tensor
-        HIPCHK(hipMemcpyAsync(q.rays, rays, (size_t)N * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // (q.rays and m->d_eps, the backward's own copies of the step's rays and latents, are written by the copy blocks of the
+        //  entropy_finalize launch below - the forward itself reads the caller's)
         q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true; q.points = false;
         ++q.generation;                      // this forward now owns the one stash: older backward passes are refused
     }
@@ -285,8 +285,11 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     if (m->timing) { HIPCHK(hipEventRecord(m->fr1[m->fwd_launches % kFwdRing], st)); ++m->fwd_launches; }
     if ((flags & CFNERF_F_STASH) && raw_opt)
         HIPCHK(hipMemcpyAsync(raw_opt, m->stash.raw, (size_t)a.P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (train)
-        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, st));
+    if (train) {
+        const bool keep = flags & CFNERF_F_STASH;
+        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, keep ? m->d_eps : nullptr, rays,
+                                       keep ? m->stash.rays : nullptr, N * 11, st));
+    }
     return CFNERF_OK;
 }
 
@@ -346,7 +349,7 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
         q.n_tiles = (P + kTileM - 1) / kTileM;
         a.n_tiles = q.n_tiles;
         a.raw = q.raw;                       // the backward reads the model's OWN copy
-        HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (!train) HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));   // (else: entropy_finalize keeps them)
         q.N = 1; q.S = (int)P; q.K = K; q.flags = flags; q.valid = true; q.points = true;
         ++q.generation;
     }
@@ -355,7 +358,8 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
     if (flags & CFNERF_F_STASH)
         HIPCHK(hipMemcpyAsync(raw, m->stash.raw, (size_t)P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train)
-        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out, st));
+        HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out,
+                                       (flags & CFNERF_F_STASH) ? m->d_eps : nullptr, nullptr, nullptr, 0, st));
     return CFNERF_OK;
 }
 

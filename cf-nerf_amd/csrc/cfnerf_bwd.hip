@@ -294,13 +294,13 @@ struct EpiPre {
 
 template <int NTW>
 __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int nt0, int nts, const uint32_t* __restrict__ mbits,
-                                             const float* __restrict__ dbp) {
+                                             const float* __restrict__ dbp, bool first) {
     const int lane = lane_id_opaque();
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         int nt = nt0 + j * nts;
         if (nt >= nt_total) nt = nt0 < nt_total ? nt0 : 0;      // clamped: value unused
-        e.db[j] = dbp[nt * 32 + (lane & 31)];
+        e.db[j] = first ? 0.f : dbp[nt * 32 + (lane & 31)];    // (uniform) a workgroup's first tile STARTS its partial rows: no memset of [n_wg, nb] per step
         e.mb[j] = (mbits != nullptr) ? mbits[nt * 64 + lane] : 0xffffffffu;      // bit 31 - e: element e of the fragment
     }
 }
@@ -416,6 +416,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
         const int chunk = (int)(tile - ray * cpr);
         const int64_t p0 = ray * (int64_t)Sn + (int64_t)chunk * kTileM;
         const int rows_valid = min(kTileM, Sn - chunk * kTileM);
+        const bool first = tile == (int64_t)blockIdx.x;        // this workgroup's first tile: its bias-partial rows start here
         // ---- 0. g_theta tile -> act[:, 0:128).  A thread's eight 16-byte pieces are requested in BATCHES before the first of a batch is
         //      consumed (round 4): as one plain loop the compiler kept it rolled - load, s_waitcnt vmcnt(0), ds_write, next piece - i.e.
         //      eight serialised memory round trips at the top of every tile, sixteen with two k-parts (that, not the bytes, was the ~40 us
@@ -470,7 +471,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
         if (tid < kThetaAll) {                                 // bias gradients of the flow-parameter heads
             float s = 0.f;
             for (int r = 0; r < kTileM; ++r) s += act_load<PREC>(act + r * LD, LD, tid);
-            dbp[A.db_theta + tid] += s;
+            dbp[A.db_theta + tid] = (first ? 0.f : dbp[A.db_theta + tid]) + s;
         }
         // ---- 1. dh_rgb = g_theta_rgb * [amor_d; diag1; diag2; b]   ;   dh_alpha likewise
         if (T.bt_fr.nt > 2 || T.bt_fa.nt > 2) {
@@ -479,8 +480,8 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             f32x16 accR[2][1], accA[2][1];
             EpiPre<1> eR, eA;
             acc_zero(accR); acc_zero(accA);
-            epi_prefetch<1>(eR, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
-            epi_prefetch<1>(eA, T.bt_fa.nt, wave, kWaves, nullptr, dbp + A.db_ha);
+            epi_prefetch<1>(eR, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr, first);
+            epi_prefetch<1>(eA, T.bt_fa.nt, wave, kWaves, nullptr, dbp + A.db_ha, first);
             mma_any<1, PREC, (W > 256 ? 3 : 2)>(accR, kload(T.bt_fr), wave, kWaves, wp, wp16, act, LD);
             mma_any<1, PREC, (W > 256 ? 3 : 2)>(accA, kload(T.bt_fa), wave, kWaves, wp, wp16, act, LD, kThetaRgb);
             __syncthreads();
@@ -494,10 +495,10 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             acc_zero(acc);
             const bool is_rgb = wave < 2;
             if (is_rgb) {
-                epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr);
+                epi_prefetch<1>(e, T.bt_fr.nt, wave, kWaves, nullptr, dbp + A.db_hr, first);
                 mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_fr), wave, kWaves, wp, wp16, act, LD);
             } else {
-                epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha);
+                epi_prefetch<1>(e, T.bt_fa.nt, wave - 2, kWaves, nullptr, dbp + A.db_ha, first);
                 mma_any<1, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_fa), wave - 2, kWaves, wp, wp16, act, LD, kThetaRgb);
             }
             __syncthreads();
@@ -511,7 +512,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             f32x16 acc[2][NTV];
             EpiPre<NTV> e;
             acc_zero(acc);
-            epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v);
+            epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v, first);
             mma_any<NTV, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_hr), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
@@ -523,7 +524,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat);
+            epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat, first);
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_vf), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
             store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
@@ -535,7 +536,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(D - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (D - 1) * W, first);
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ft), wave, kWaves, wp, wp16, act, LD);
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ha), wave, kWaves, wp, wp16, hs, HLD);
             __syncthreads();
@@ -558,7 +559,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             f32x16 acc[2][NTW];
             EpiPre<NTW> e;
             acc_zero(acc);
-            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W);
+            epi_prefetch<NTW>(e, NT, wave, kWaves, mb_all + ((size_t)(l - 1) * n_tiles + tile) * kMbStride, dbp + A.db_h + (l - 1) * W, first);
             if (kBPre) {
                 mma_seg_pre<NTW>(acc, kload(T.bt_trunk[l]), wave, kWaves, wp, act, LD, bpre);
                 if (l > 1) b_prefetch<NTW>(kload(T.bt_trunk[l - 1]), wave, kWaves, wp, bpre);
@@ -1446,8 +1447,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[1], st));
 
     // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
-    BHIP(hipMemsetAsync(q.dbp, 0, (size_t)n_wg * B.nb * sizeof(float), st));
-    BwdArgs ba{};
+    BwdArgs ba{};                                              // (q.dbp needs no memset: every launched workgroup starts its row on its first tile)
     ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
     ba.g_theta = q.g_theta; ba.g_parts = ksplit; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;      // (points: ONE "ray" of S = P samples)

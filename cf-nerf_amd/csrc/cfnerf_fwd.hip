@@ -681,8 +681,19 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
 }
 
 // loss_entropy = mean(base_a) - mean(ld_a) + mean(base_rgb) - mean(ld_rgb)      (MOD:268,283,286)
+// Blocks past the first are a copy engine: the backward reads the model's OWN copies of the step's rays and latents (the caller may
+// drop its tensors), and as blocks of this launch the two copies cost no launches of their own (they were two hipMemcpyAsync, ~4 us
+// of stream time each, in front of every forward).
 __global__ void entropy_finalize_kernel(const float* partials, int n_part, const float* flat, const float* eps,
-                                        int K, double count /* P*K */, float* out) {
+                                        int K, double count /* P*K */, float* out, float* eps_keep, const float* rays, float* rays_keep,
+                                        int64_t n_rays_floats) {
+    if (blockIdx.x > 0) {
+        const int64_t i = ((int64_t)blockIdx.x - 1) * blockDim.x + threadIdx.x;
+        if (i < n_rays_floats) rays_keep[i] = rays[i];
+        return;
+    }
+    if (eps_keep != nullptr)
+        for (int i = threadIdx.x; i < K * 4; i += blockDim.x) eps_keep[i] = eps[i];
     __shared__ double sh[2][256];
     double s0 = 0, s1 = 0;
     for (int i = threadIdx.x; i < n_part; i += blockDim.x) { s0 += partials[2 * i]; s1 += partials[2 * i + 1]; }
@@ -1168,8 +1179,11 @@ int fused_fwd_max_grid(int W, int ha, int n_cu) {
 }
 
 hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
-                                   double count, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(256), 0, st, partials, n_part, flat, eps, K, count, out);
+                                   double count, float* out, float* eps_keep, const float* rays, float* rays_keep, int64_t n_rays_floats,
+                                   hipStream_t st) {
+    const unsigned copy_blocks = (rays_keep != nullptr) ? (unsigned)((n_rays_floats + 255) / 256) : 0u;
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1 + copy_blocks), dim3(256), 0, st, partials, n_part, flat, eps, K, count, out, eps_keep,
+                       rays, rays_keep, rays_keep != nullptr ? n_rays_floats : 0);
     return hipGetLastError();
 }
 

@@ -50,7 +50,8 @@ hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, 
 hipError_t fused_fwd_set_attributes(int W, int ha, int* per_cu_out);      // per device, at model creation
 int fused_fwd_max_grid(int W, int ha, int n_cu);
 hipError_t launch_entropy_finalize(const float* partials, int n_part, const float* flat, const float* eps, int K,
-                                   double count, float* out, hipStream_t st);
+                                   double count, float* out, float* eps_keep, const float* rays, float* rays_keep, int64_t n_rays_floats,
+                                   hipStream_t st);
 hipError_t launch_composite(const float* raw, const float* z, const float* d, int64_t N, int S, int K, int wb,
                             float* rgb, float* disp, float* depth, float* weights, hipStream_t st);
 hipError_t launch_rays_setup(int H, int Wd, float focal, const RaysC2W& c2w, int use_c2w, const float* ro, const float* rd,
