@@ -56,6 +56,49 @@ def test_composite_backward_vs_oracle_autograd(N, S, K, wb):
         close(got.cpu(), ref.float(), atol=2e-5 * float(ref.abs().max()), rtol=2e-3, what=f"d_raw {use}")
 
 
+def _composite_fuzz_seeds():
+    """12 draws in the suite; CFNERF_FUZZ_SEEDS=a-b widens them for a one-off soak (like tests/test_hip_train.py)"""
+    import os
+    span = os.environ.get("CFNERF_FUZZ_SEEDS")
+    if span:
+        a, b = (int(v) for v in span.split("-"))
+        return list(range(a, b))
+    return list(range(12))
+
+
+@pytest.mark.parametrize("seed", _composite_fuzz_seeds())
+def test_composite_random_shapes_forward_and_backward_vs_oracle(seed):
+    """The standalone raw2outputs kernel and its adjoint at RANDOM (N, S, K): every latent-group size (K below / at / above 4, 8, 16,
+    64 - ragged last groups, both transcendental paths, more than one 64-latent pass), every chunking of S (one ragged chunk, exact
+    multiples of 64, many chunks), rays that end a tensor (the bounds check of the LDS-DMA descriptor), with and without the
+    white background, cotangents for every output incl. `weights`."""
+    rng = np.random.default_rng(4242 + seed)
+    K = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 40, 63, 64, 65, 72, 100, 128]))
+    S = int(rng.choice([2, 3, 17, 63, 64, 65, 100, 127, 128, 129, 192, 200, 257, 320]))
+    N = int(rng.integers(1, 10))
+    wb = bool(rng.integers(0, 2))
+    raw = torch.tensor(rng.standard_normal((N, S, K, 4)) * 1.5, dtype=torch.float32)
+    if rng.integers(0, 2):
+        raw[0, :, :, 3] = 25.0                               # softplus threshold branch, opaque ray
+    if N > 1 and rng.integers(0, 2):
+        raw[N - 1, :, :, 3] = -30.0                          # the LAST ray of the tensor is empty
+    z = torch.sort(torch.tensor(rng.uniform(0.05, 1.0, (N, S)), dtype=torch.float32), -1).values
+    d = torch.tensor(rng.standard_normal((N, 3)), dtype=torch.float32)
+    G = [torch.tensor(rng.standard_normal(s), dtype=torch.float32) for s in ((N, 3, K), (N, K), (N, S, K), (N, K))]
+    use = (1, 0, int(rng.integers(0, 2)), int(rng.integers(0, 2)))        # rgb always; weights / depth at random (disp: see the test above)
+    r64 = raw.double().requires_grad_(True)
+    outs = O.raw2outputs(r64, z.double(), d.double(), wb)
+    (ref,) = torch.autograd.grad(sum((o * g.double()).sum() for o, g, u in zip(outs, G, use) if u), r64)
+    rg = raw.to(DEV).requires_grad_(True)
+    outs_h = cfnerf_amd.raw2outputs(rg, z.to(DEV), d.to(DEV), 0, wb)
+    for o, oo, name in zip(outs_h, outs, ("rgb_map", "disp_map", "weights", "depth_map")):
+        if name != "disp_map":
+            close(o, oo.float(), what=f"{name} N={N} S={S} K={K}")
+    (got,) = torch.autograd.grad(sum((o * g.to(DEV)).sum() for o, g, u in zip(outs_h, G, use) if u), rg)
+    assert torch.isfinite(got).all()
+    assert _rel_to_max(got.cpu(), ref) <= 2e-5, (N, S, K, wb, use, _rel_to_max(got.cpu(), ref))
+
+
 def test_composite_backward_matches_torch_autograd_contract():
     """no gradient requested -> zeros; raw without requires_grad -> plain tensors (no graph), like any torch function"""
     raw = torch.randn(3, 128, 2, 4, device=DEV)
