@@ -733,12 +733,13 @@ __global__ void entropy_finalize_kernel(const float* partials, int n_part, const
 // not by memory), the hardware forms from there on (Num<FAST>).
 constexpr int kCompKB = 64;       // latents of one pass over a ray's chunks (their carries and sums wait in LDS, entry = lane)
 template <int KG, bool FAST>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(kThreads, FAST ? 4 : 3)      // (the LDS block leaves room for 4 workgroups per CU: keep the registers there too)
 void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d,
                       int64_t N, int S, int K, int white_bkgd, float* rgb_map, float* disp_map, float* depth_map,
                       float* weights) {
     using M = Num<FAST>;
     using St = CompStage<KG>;
+    constexpr int U = (KG == 8) ? 4 : 1;                     // groups per round of the weights turn-around (32 latents = one 128-byte line per sample)
     __shared__ __attribute__((aligned(16))) float stage_all[kWaves][St::kQuads * 4];
     __shared__ float sums_all[kWaves][6][kCompKB];           // [0] transmittance entering the next chunk, [1..5] rgb / depth / acc sums
     const int lane = lane_id();
@@ -774,7 +775,14 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
                 const float dz = (s == S - 1) ? 1e1f : zr[s + 1] - zv;
                 dist = dz * dnorm;
             }
-            for (int gi = 0; gi < kn; gi += KG) {
+            for (int gf = 0; gf < kn; gf += KG * U) {
+                float wrow_keep[KG * U];                     // (U > 1) this sample's weights of up to 32 latents, for full-line stores
+#pragma unroll
+                for (int i = 0; i < KG * U; ++i) wrow_keep[i] = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < U; ++gq) {
+                const int gi = gf + gq * KG;
+                if (gi >= kn) continue;                      // (uniform)
                 const int g0 = kb + gi;
                 St::fetch(rsrc, lds0, voff, ch, g0, K);
                 // lane q < KG: latent g0 + q
@@ -801,12 +809,12 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
                     }
                 }
                 if (lane < KG) { sums[0][slot] = carv; sums[1][slot] = acc0; sums[2][slot] = acc1; sums[3][slot] = acc2; sums[4][slot] = accd; sums[5][slot] = acca; }
-                if (weights != nullptr && valid) {
-                    // (K > 4: 32-byte pieces at a pitch of 4 K bytes.  The same bytes as one contiguous 2-KB block per chunk and group -
-                    //  a timing-only build, wrong layout - took 289 instead of 414 us at K = 32: that is what the pieces cost; gathering
-                    //  four groups per sample for full 128-byte lines needs 8 KB more LDS per wave = half the resident waves. Not built.)
+                if (U > 1 && vec_w) {
+#pragma unroll
+                    for (int q = 0; q < KG; ++q) wrow_keep[gq * KG + q] = wv[q];
+                } else if (weights != nullptr && valid) {
                     float* wrow = weights + (ray * S + s) * (int64_t)K + g0;
-                    if (vec_w) {
+                    if (vec_w) {                             // (K <= 4: a sample's row is one 16-byte store, rows adjacent)
 #pragma unroll
                         for (int q = 0; q < KG; q += 4)
                             if (gi + q < kn) { f32x4 o; o[0] = wv[q]; o[1] = wv[q + 1]; o[2] = wv[q + 2]; o[3] = wv[q + 3]; *reinterpret_cast<f32x4*>(wrow + q) = o; }
@@ -814,6 +822,32 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
 #pragma unroll
                         for (int q = 0; q < KG; ++q)
                             if (gi + q < kn) wrow[q] = wv[q];
+                    }
+                }
+                }
+                if (U > 1 && vec_w) {
+                    // Up to 32 latents = 128 bytes per sample: turned around in the (now free) LDS block so that 8 lanes write one sample's
+                    // full line - a lane's own 16- or 32-byte pieces at a pitch of 4 K bytes took 414 instead of ~290 us at K = 32
+                    // (a timing-only build with a contiguous layout).  Quad kq of sample sl sits at sl * 8 + (kq ^ swz(sl)).
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wave_lds_turn();
+#pragma unroll
+                    for (int kq = 0; kq < 8; ++kq) {
+                        f32x4 o; o[0] = wrow_keep[kq * 4]; o[1] = wrow_keep[kq * 4 + 1]; o[2] = wrow_keep[kq * 4 + 2]; o[3] = wrow_keep[kq * 4 + 3];
+                        *reinterpret_cast<f32x4*>(stage + (lane * 8 + (kq ^ my_swz)) * 4) = o;
+                    }
+                    wave_lds_turn();
+                    float* wblk = weights + (ray * S + (int64_t)ch * 64) * K + kb + gf;
+                    f32x4 ov[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int sl = j * 8 + (lane >> 3), kq = lane & 7;
+                        ov[j] = *reinterpret_cast<const f32x4*>(stage + (sl * 8 + (kq ^ St::swz(sl))) * 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int sl = j * 8 + (lane >> 3), kq = lane & 7;
+                        if (ch * 64 + sl < S && gf + kq * 4 < kn) *reinterpret_cast<f32x4*>(wblk + (int64_t)sl * K + kq * 4) = ov[j];
                     }
                 }
             }
@@ -832,6 +866,7 @@ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z
         wave_lds_turn();
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // ray set-up (render() RUN:129-158; get_rays HLP:288-297; ndc_rays HLP:360-377)
