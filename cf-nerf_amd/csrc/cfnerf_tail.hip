@@ -120,7 +120,10 @@ struct GReg {
 #pragma unroll
         for (int i = 0; i < 84; ++i) g[i] = 0.f;
     }
-    __device__ __forceinline__ void add(int i, float v) { g[i] += v; }
+    __device__ __forceinline__ void add(int i, float v) {
+#pragma clang fp contract(fast)      // the add must carry the flag too, or `g[i] += a * b` of flows_adjoint stays a v_mul + v_add pair (round 4: it did)
+        g[i] += v;
+    }
     __device__ __forceinline__ float get(int i) const { return g[i]; }
 };
 // One row of d loss / d theta (the pre-activation outputs of the flow-parameter heads), in the [P,128] layout of theta:
