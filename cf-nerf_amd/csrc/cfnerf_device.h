@@ -591,7 +591,11 @@ template <bool FAST> struct Num {
 // deviations of the alpha-path gradients it was suspected of are the conditioning of those cases, see tests/util_hip.py.)
 __device__ __forceinline__ float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float t_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-__device__ __forceinline__ float t_tanh(float x) { return 1.f - 2.f * t_rcp(1.f + t_exp(2.f * x)); }
+// (one multiply for the exponent - (2 x) * log2(e) and x * (2 log2(e)) are the same fp32 number, doubling is exact - and one fma for
+//  1 - 2 r, likewise the same number as the separate multiply and subtract: 3 + 2 instead of 5 + 2 instructions, bit-identical values)
+__device__ __forceinline__ float t_tanh(float x) {
+    return __builtin_fmaf(-2.f, t_rcp(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f)), 1.f);
+}
 __device__ __forceinline__ float t_sigmoid(float x) { return t_rcp(1.f + t_exp(-x)); }
 
 
