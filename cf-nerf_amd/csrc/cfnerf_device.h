@@ -572,7 +572,7 @@ template <bool FAST> struct Num {
     static __device__ __forceinline__ float exp(float x) { return FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x); }
     static __device__ __forceinline__ float ln(float x) { return FAST ? __builtin_amdgcn_logf(x) * 0.6931471805599453f : logf(x); }
     static __device__ __forceinline__ float tanh(float x) {
-        return FAST ? 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f)) : tanhf(x);
+        return FAST ? __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f)), 1.f) : tanhf(x);   // (fma: the same number as 1 - 2 r, doubling is exact)
     }
     static __device__ __forceinline__ float sigmoid(float x) {
         return FAST ? __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)) : sigmoid_f(x);
