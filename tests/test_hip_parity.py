@@ -521,6 +521,35 @@ def test_sample_points_kernel_vs_reference_golden(golden):
     close(pts, g["pts"], atol=1e-6, rtol=1e-6, what="pts")
 
 
+@pytest.mark.parametrize("N,S,lindisp,jitter", [(1, 128, False, True), (7, 64, False, True), (5, 70, True, True), (9, 2, False, False),
+                                                 (3, 200, True, False), (130, 65, False, True), (2, 1000, False, True)])
+def test_sample_points_kernel_vs_oracle_ragged(N, S, lindisp, jitter):
+    """RUN:510-534 standalone (one wave per ray, pts rows through LDS): every chunking of S, ray counts that do not fill a workgroup,
+    lindisp, with and without the stratified jitter; z bit for bit the oracle's fp32 arithmetic up to the last place of the lerp."""
+    from cfnerf_amd import _lib as L
+    rng = np.random.default_rng(N * 31 + S)
+    ro = torch.tensor(rng.standard_normal((N, 3)), dtype=torch.float32)
+    rd = torch.tensor(rng.standard_normal((N, 3)), dtype=torch.float32)
+    near = torch.tensor(rng.uniform(0.5, 1.5, (N, 1)), dtype=torch.float32)
+    far = near + torch.tensor(rng.uniform(1.0, 5.0, (N, 1)), dtype=torch.float32)
+    packed = torch.cat([ro, rd, near, far, rd / rd.norm(dim=-1, keepdim=True)], -1).contiguous()
+    tv = torch.linspace(0., 1., steps=S)
+    tr = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32) if jitter else None
+    z_o = O.sample_z(near, far, tv, lindisp, tr)
+    pts_o = ro[:, None, :] + rd[:, None, :] * z_o[..., None]
+    z = torch.full((N, S), float("nan"), device=DEV)
+    pts = torch.full((N, S, 3), float("nan"), device=DEV)
+    packed_d, tv_d, tr_d = packed.to(DEV), tv.to(DEV), (tr.to(DEV) if jitter else None)      # (kept alive: the calls take raw pointers)
+    L.check(L.lib().cfnerf_sample_points(L.ptr(packed_d), L.ptr(tv_d), L.ptr(tr_d) if jitter else None, L.F_LINDISP if lindisp else 0,
+                                         N, S, L.ptr(z), L.ptr(pts), L.stream()), "sample_points")
+    close(z, z_o, atol=1e-6, rtol=1e-6, what="z_vals")
+    close(pts, pts_o, atol=2e-6, rtol=2e-6, what="pts")
+    z2 = torch.full((N, S), float("nan"), device=DEV)          # z only (pts == NULL)
+    L.check(L.lib().cfnerf_sample_points(L.ptr(packed_d), L.ptr(tv_d), L.ptr(tr_d) if jitter else None, L.F_LINDISP if lindisp else 0,
+                                         N, S, L.ptr(z2), None, L.stream()), "sample_points")
+    assert torch.equal(z2, z)
+
+
 def test_seeded_create_nerf_matches_reference_construction(golden):
     """torch.manual_seed(1234); create_nerf(args) -> the reference's initial state_dict and eval latents (G11)."""
     g = golden("g11_seeded_init")
