@@ -172,7 +172,8 @@ CFNERF_API int cfnerf_sample_pdf(const float* rays, const float* t_vals, const f
 CFNERF_API int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_t P, int K, int flags,
                        float* raw, float* entropy_out, cfnerf_stream s);
 
-/* replaces: raw2outputs() RUN:411-454 as a standalone call.  raw [N,S,K,4], z_vals [N,S], rays_d [N,3] */
+/* replaces: raw2outputs() RUN:411-454 as a standalone call.  raw [N,S,K,4] (16-byte aligned, S * K * 16 bytes per ray < 2 GiB: it is
+ * fetched through one buffer descriptor per ray), z_vals [N,S], rays_d [N,3]; any K >= 1, any S >= 1 */
 CFNERF_API int cfnerf_composite_fwd(const float* raw, const float* z_vals, const float* rays_d,
                          int64_t N, int S, int K, int white_bkgd,
                          float* rgb_map, float* disp_map, float* depth_map, float* weights_opt,
