@@ -9,7 +9,9 @@ set +e
 rm -rf "$O"/q_*
 i=0
 for c in "$@"; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/q_$i" -o pmc -- python3 "$R/bench.py" --no-cpu-baseline --no-alt --steps 3 --warmup 1 ${PB_ARGS:-} > "$O/q_$i.log" 2>&1
+  # (bounded: a counter group the hardware cannot collect in one pass makes rocprofv3 abort and then sit in its finaliser - that cost
+  #  a 25-minute gpurun call in round 4; FETCH_SIZE / WRITE_SIZE go in passes of their own, like tools/profile_round.sh does)
+  timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/q_$i" -o pmc -- python3 "$R/bench.py" --no-cpu-baseline --no-alt --steps 3 --warmup 1 ${PB_ARGS:-} > "$O/q_$i.log" 2>&1
   i=$((i+1))
 done
 python3 - "$O" "${PB_KERNEL:-cfnerf}" <<'PY'
