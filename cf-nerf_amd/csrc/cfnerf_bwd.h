@@ -15,6 +15,7 @@ struct TailArgs {
     int64_t N, P;
     int32_t S, K, flags;
     int32_t ksplit;                                       // waves per ray: wave (ray, part) handles latents [part*Kp, (part+1)*Kp)
+    int32_t merge;                                        // ksplit 2 or 4: a ray's parts share a workgroup and add their g_theta rows in LDS: ONE part leaves
     float *g_theta, *gms_partials;                        // [ksplit][P,128] partial theta gradients (summed by bwd_data's loader), [N*ksplit, 8]
 };
 

@@ -1435,8 +1435,10 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
         ksplit = tail_parts(N, q.K, std::min(m->n_cu, kMaxCu));      // (never more parts than the workspace was carved for)
         ta.ksplit = ksplit;
+        ta.merge = (ksplit == 2 || ksplit == 4) ? 1 : 0;         // the parts of a ray are waves of one 4-wave workgroup: summed in LDS
         gms_rows = N * ksplit;
         BHIP(launch_tail_bwd(ta, N, ksplit, st));
+        if (ta.merge) ksplit = 1;                                // ... and backward-data sees ONE g_theta part
     } else {
         unsigned grid = 0;
         BHIP(launch_flows_bwd(q.raw, q.theta, m->d_eps, m->flat, d_out, d_entropy, P, q.K, q.g_theta, q.gms, &grid, st));

@@ -150,15 +150,22 @@ __global__ __launch_bounds__(kThreads, 2)
 void tail_bwd_kernel(const TailArgs A) {
 #pragma clang fp contract(fast)
     __shared__ float carry[kWaves][kMaxK];
+    // merge (ksplit 2 or 4, so a ray's parts are waves of ONE workgroup): the parts past the first publish their 84 partial sums per
+    // sample here and the first adds them before it writes the row - one g_theta part leaves the kernel, and backward-data neither reads
+    // a second [P,128] array nor writes the sum back (K = 64: +60 MB read, +65 MB written, +4.9 % of that kernel by counters).
+    __shared__ float gsh[kWaves - 1][84][64];
     const int lane = lane_id_opaque(), wave = wave_id();
     GReg gth;
     // one wave per (ray, k-part): a ray's K latent samples are independent up to the sums over k, which are left to the
     // consumers (bwd_data adds the partial g_theta's while loading them, reduce_gms adds the rows), so small batches and
     // large K still fill the chip (this kernel runs one wave per SIMD: ~360 registers)
     const int64_t unit = (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t ray = unit / A.ksplit;
-    const int part = (int)(unit - ray * A.ksplit);
-    if (ray >= A.N) return;
+    const int64_t ray_u = unit / A.ksplit;
+    const int part = (int)(unit - ray_u * A.ksplit);
+    const bool merge = A.merge != 0;
+    const bool live = ray_u < A.N;
+    if (!live && !merge) return;                           // (merge: every wave of the workgroup keeps step with the barriers below)
+    const int64_t ray = live ? ray_u : 0;                  // (a wave past the last ray addresses ray 0 and touches nothing)
     const int S = A.S, K = A.K;
     const int Kp = (K + A.ksplit - 1) / A.ksplit, k_lo = part * Kp, k_hi = min(K, k_lo + Kp);
     float* __restrict__ g_theta_out = A.g_theta + (size_t)part * A.P * kThetaAll;
@@ -176,6 +183,7 @@ void tail_bwd_kernel(const TailArgs A) {
 
     const int nch = (S + 63) / 64;
     for (int ch = nch - 1; ch >= 0; --ch) {
+        if (!live) { __syncthreads(); __syncthreads(); continue; }      // (merge only: a wave past the last ray)
         const int s = ch * 64 + lane;
         const bool valid = s < S;
         const int64_t p = ray * (int64_t)S + (valid ? s : 0);
@@ -233,8 +241,25 @@ void tail_bwd_kernel(const TailArgs A) {
 
             flows_adjoint(th, gth, gms, cur.e, a_mean, a_std, r_mean, r_std, ga, gz, cE, valid);
         }
-        if (valid) store_gtheta_row(g_theta_out + p * kThetaAll, th, gth);
+        if (merge) {
+            if (part != 0) {
+#pragma unroll
+                for (int i = 0; i < 84; ++i) gsh[wave - 1][i][lane] = gth.get(i);
+            }
+            __syncthreads();
+            if (part == 0) {
+                for (int pp = 1; pp < A.ksplit; ++pp) {    // fixed order: part 0 + part 1 (+ part 2 + part 3)
+#pragma unroll
+                    for (int i = 0; i < 84; ++i) gth.add(i, gsh[wave + pp - 1][i][lane]);
+                }
+            }
+            __syncthreads();                               // (the rows are free again)
+            if (part == 0 && valid) store_gtheta_row(A.g_theta + p * kThetaAll, th, gth);
+        } else if (valid) {
+            store_gtheta_row(g_theta_out + p * kThetaAll, th, gth);
+        }
     }
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) gms[i] = wave_sum(gms[i]);
     if (lane == 0) {
