@@ -20,14 +20,17 @@ constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over
 // waves still fit in one round (measured: a second round costs more than the shorter k-loops save); at most kTailParts, never more
 // than K / 2.  The workspace is carved for the CU count's upper bound (kMaxCu), the launch uses the device's own.
 // Round 4: the kernel fits 256 registers since it is built without the SLP vectoriser (cfnerf_tail.hip), so a SECOND wave per SIMD is
-// possible - it pays only while every part keeps >= 32 latents (K = 64 over 1024 rays: tail 0.256 -> 0.232 ms, backward-data +5 us for
-// the second partial g_theta it sums while loading; at 8 - 16 latents per part the k-loops run half empty and the extra partials cost
-// more than the tail gains: K = 32 over 512 rays at four parts +0.6 % on the step).
+// possible.  While the parts met in memory (a partial g_theta per part, summed by backward-data) it paid only with >= 32 latents per part;
+// since they meet in LDS (tail_bwd_kernel, `merge`) backward-data does not see them and the second wave pays down to 2 latents per
+// part: same-box A/B tail 57.8 -> 55.0 us (C2, K = 4), 93.4 -> 87.4 (C4, K = 16), 81.0 -> 76.5 (W512: four parts of 8), backward-data +-0.
 inline int tail_parts(int64_t n_rays, int k, int n_cu) {
     int parts = 1;
     while (parts < kTailParts && parts * 2 <= k) {
         const bool one_round = n_rays * parts * 2 <= (int64_t)n_cu * 4;
-        const bool second_wave = n_rays * parts * 2 <= (int64_t)n_cu * 8 && k / (parts * 2) >= 32;
+#ifndef CFN_TAIL_MIN_PER_PART      // (A/B builds; 32 = the rule before the parts of a ray met in LDS)
+#define CFN_TAIL_MIN_PER_PART 2
+#endif
+        const bool second_wave = n_rays * parts * 2 <= (int64_t)n_cu * 8 && k / (parts * 2) >= CFN_TAIL_MIN_PER_PART;
         if (!one_round && !second_wave) break;
         parts *= 2;
     }
