@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X-native CF-NeRF ray-batch hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C1|W512]
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C1|W512|K64]
     N > 1: one rank per GPU.  Either the driver starts the ranks (python -m torch.distributed.run --nproc-per-node N
     bench.py --gpus N ...: WORLD_SIZE is set) or - plain `python bench.py --gpus N` - this process, which has not touched
     the GPU, starts them itself as a child torch.distributed.run and relays rank 0's JSON line.
@@ -560,6 +560,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = exact-fp32 MFMA (default, the measured parity path); bf16x3 = opt-in split-bf16 MFMA mode")
     ap.add_argument("--psnr-steps", type=int, default=2000, help="train steps of the PSNR block (procedural stand-in scene)")
+    ap.add_argument("--extension", action="store_true", help="also time the coarse + fine sampling EXTENSION (`alt_config`; not in the reference, "
+                                                             "parity unpinned - off by default since round 5: the default line carries `eval` instead)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -710,7 +712,7 @@ def main():
     # the coarse + fine sampling EXTENSION (BASELINE configs 2/3/5 are worded "64 + 128"; the reference has no second pass, so
     # this is NOT the parity path and never the headline): coarse 64 -> sample_pdf -> fine 64 + 128, both loss terms
     hier = None
-    if extras:
+    if extras and args.extension:
         wh = Workload("C2", "train", rank, world, dev, "fp32", False)
         sc = wh.sc
 
@@ -732,6 +734,41 @@ def main():
                 "points_per_ray": "64 (coarse pass: sampling weights + its loss term) + 192 (fine pass)"}
         wh.net.release_workspace()
         del wh
+
+    # The OTHER half of SURVEY 8(d)'s metric, "rays/sec of eval render" (the reference's render_path_train / uncertainty maps, RUN:247-314,
+    # 1117-1131), in the default line at every GPU count, after the timed region: the C2 batch in eval mode (perturb off, fixed latents
+    # with the last one zeroed: one fused forward launch per step, rays per GPU fixed) and BASELINE config 5 - one 800 x 800 image at
+    # K = 32 with the K-statistics (mean / uncertainty / disparity / depth) reduced inside the kernel, rows tiled across the ranks
+    # with no exchange.  Both timed like the headline: barrier + device sync on both sides, max over ranks.
+    evalb = None
+    if not args.no_alt and name == "C2" and args.precision == "fp32" and mode == "train" and not force_dist:
+        wl.__dict__.pop("trainer", None)
+        wl.net.release_workspace()
+        we = Workload("C2", "eval", rank, world, dev, "fp32", False)
+        e_steps = max(10, min(50, args.steps))
+        dte = max_over_ranks(timed(we, e_steps, 3, sync))
+        e_fwd = we.fwd_mean_ms(e_steps)
+        fle = we.fwd_flops()
+        evalb = {"metric": "rays/sec (eval render, fused forward)",
+                 "config2_eval": {"workload": we.describe("fp32"), "value": we.n * world * e_steps / dte, "unit": "rays/s", "steps": e_steps,
+                                  "ms_per_step": dte / e_steps * 1e3, "fwd_launch_ms": e_fwd,
+                                  "roofline": {"bound": "mfma", "kernel": "fused_fwd_kernel<256,rays,eval>", "achieved": fle / (e_fwd * 1e-3) / 1e12,
+                                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fle / (e_fwd * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                               "flops_per_launch": fle}}}
+        del we
+        w5 = Workload("C5", "eval", rank, world, dev, "fp32", False)
+        n_img = 2
+        dt5 = max_over_ranks(timed(w5, n_img, 1, sync))
+        f5 = w5.fwd_mean_ms(n_img)
+        sc5 = w5.sc
+        fl5 = w5.fwd_flops()
+        evalb["config5_full_image"] = {"workload": w5.describe("fp32"), "value": sc5["H"] * sc5["W"] * n_img / dt5, "unit": "rays/s", "images": n_img,
+                                       "s_per_image": dt5 / n_img, "fwd_launch_ms": f5,
+                                       "outputs": "fused K-statistics per pixel: K-mean rgb, uncertainty std_K n/(n-1) (RUN:1129-1130), mean disparity, mean depth",
+                                       "roofline": {"bound": "mfma", "kernel": "fused_fwd_kernel<256,rays,eval>", "achieved": fl5 / (f5 * 1e-3) / 1e12,
+                                                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl5 / (f5 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                                    "flops_per_launch": fl5, "note": "this rank's launch (its rows of the image)"}}
+        del w5
 
     # PSNR, the second half of the headline metric, on the synthetic stand-in scene - at EVERY GPU count (default train run only): one rank
     # trains 1024-ray batches, N ranks train world x 1024-ray global batches through the sharded ray pool + the Trainer's all-reduce.
@@ -799,6 +836,8 @@ def main():
             out["step_frac_of_peak"] = 3 * fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF
         if psnr is not None:
             out["psnr"] = psnr
+        if evalb is not None:
+            out["eval"] = evalb
         if alt is not None:
             out["alt_precision"] = alt
         if cfg4 is not None:

@@ -67,6 +67,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python cf-nerf_amd/build.py` (needs hipcc). "
                 "The CF-NeRF hot path has no CPU or PyTorch fallback.")
+        if os.environ.get("CFNERF_LIB"):
+            import sys
+            print(f"cf-nerf_amd: warning: CFNERF_LIB is set - loading {LIB_PATH} instead of the in-tree libcfnerf_hip.so "
+                  "(development aid for same-box A/B runs of two builds)", file=sys.stderr, flush=True)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)      # AttributeError here = header / library out of sync

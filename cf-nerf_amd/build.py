@@ -10,13 +10,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcfnerf_hip.so")
 CONSUMER = os.path.join(OBJ, "abi_consumer")
+HOOKS = os.path.join(OBJ, "libcfnerf_testhooks.so")        # TEST artefact (tests/cfnerf_debug.h); the product never loads it
 SOURCES = ["cfnerf_fwd.hip", "cfnerf_bwd.hip", "cfnerf_tail.hip", "cfnerf_abi.hip"]
 # per-file flags: the flow-adjoint kernels are long straight-line scalar code that the SLP vectoriser makes slower (cfnerf_tail.hip)
 EXTRA_FLAGS = {"cfnerf_tail.hip": ["-fno-slp-vectorize"]}
 # -ffp-contract=off: the sampling / encoding arithmetic must round like the reference's separate
 # torch ops (an fma in pts = o + d*z moves sin(2^9 x) by ~3e-5); MFMA code is unaffected.
-# -fvisibility=hidden: the dynamic symbol table holds the CFNERF_API entry points of include/cfnerf.h (+ the test hooks of
-# tests/cfnerf_debug.h) and nothing else (tests/test_abi_cpu.py compares `nm -D` with the headers).
+# -fvisibility=hidden + the linker version script: the dynamic symbol table holds the CFNERF_API entry points of include/cfnerf.h and
+# nothing else (tests/test_abi_cpu.py compares `nm -D` with the header).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -57,13 +58,36 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "cfnerf_exports.map"), "-o", LIB, *objs])
-    # the plain-C consumer of the ABI is a TEST artefact: its build must never fail the library's (a box without the C HIP headers,
-    # another ROCm layout); tests/test_hip_abi_consumer.py reports a missing binary itself
-    try:
-        build_consumer(force=force, verbose=verbose)
-    except Exception as e:                      # noqa: BLE001
-        print(f"cf-nerf_amd/build.py: warning: tests/abi_consumer.c was not built ({str(e).splitlines()[0]})", file=sys.stderr)
+    # the plain-C consumer of the ABI and the test-hooks library are TEST artefacts: their builds must never fail the library's (a box
+    # without the C HIP headers, another ROCm layout); the tests that need them report a missing file themselves
+    for what, fn in (("tests/abi_consumer.c", build_consumer), ("tests/csrc/cfnerf_testhooks.hip", build_test_hooks)):
+        try:
+            fn(force=force, verbose=verbose)
+        except Exception as e:                      # noqa: BLE001
+            print(f"cf-nerf_amd/build.py: warning: {what} was not built ({str(e).splitlines()[0]})", file=sys.stderr)
     return LIB
+
+
+def build_test_hooks(force=False, verbose=False):
+    """tests/csrc/cfnerf_testhooks.hip -> cf-nerf_amd/build/libcfnerf_testhooks.so: the six cfnerf_debug_* hooks of tests/cfnerf_debug.h,
+    compiled against the library's internal headers (header-only host planners + the layout of the opaque handle).  Not linked against
+    libcfnerf_hip.so and never loaded by the product."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "csrc", "cfnerf_testhooks.hip")
+    if not os.path.exists(src):
+        raise RuntimeError("no tests/csrc/cfnerf_testhooks.hip")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(root, "include", "cfnerf.h"), os.path.join(root, "tests", "cfnerf_debug.h")]
+    if not (force or _newer(HOOKS, [src] + headers)):
+        return HOOKS
+    os.makedirs(OBJ, exist_ok=True)
+    cmd = [_hipcc(), *FLAGS, "-I" + CSRC, "-I" + os.path.join(root, "include"), "-shared", src, "-o", HOOKS]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("test-hooks build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return HOOKS
 
 
 def build_consumer(force=False, verbose=False):

@@ -453,73 +453,4 @@ float cfnerf_timing_last_ms(cfnerf_model* m, int which) {
 
 }  // extern "C"
 
-// ---- test hooks (NOT part of the ABI of include/cfnerf.h; declared in tests/cfnerf_debug.h) -------------------
-extern "C" {
-// host-side packing with the same index map the device kernel uses (CPU tests of the operand layout)
-CFNERF_API int64_t cfnerf_debug_packed_floats(const cfnerf_cfg* cfg) {
-    if (!cfg || validate_cfg(*cfg)) return -1;
-    ParamLayout L = build_layout(*cfg);
-    return build_pack_plan(*cfg, L).tab.packed_floats;
-}
-CFNERF_API int cfnerf_debug_pack_host(const cfnerf_cfg* cfg, const float* flat_host, float* packed_host) {
-    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
-    ParamLayout L = build_layout(*cfg);
-    PackPlan P = build_pack_plan(*cfg, L);
-    std::memset(packed_host, 0, (size_t)P.tab.packed_floats * sizeof(float));
-    for (const PackDesc& d : P.descs) {
-        const uint32_t n = d.n_cols ? d.n_rows * d.n_cols : d.n_rows;
-        for (uint32_t i = 0; i < n; ++i) {
-            uint32_t src, dst;
-            pack_map(d, i, &src, &dst);
-            packed_host[dst] = flat_host[src];
-        }
-    }
-    return CFNERF_OK;
-}
-// copy a stash / backward-workspace buffer of the last STASH forward into dst (device), for tests
-CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s) {
-    if (!m || !m->stash.valid) return -1;
-    Stash& q = m->stash;
-    const int W = m->cfg.netwidth;
-    const int64_t P = q.N * (int64_t)q.S;
-    std::string n = name;
-    const float* src = nullptr; int64_t cnt = 0;
-    if (n == "h") { src = q.h + (size_t)layer * P * W; cnt = P * W; }
-    else if (n == "g_h") { src = q.g_h + (size_t)layer * P * W; cnt = P * W; }
-    else if (n == "feat") { src = q.feat; cnt = P * W; }
-    else if (n == "g_feat") { src = q.g_feat; cnt = P * W; }
-    else if (n == "v") { src = q.v; cnt = P * (W / 2); }
-    else if (n == "g_v") { src = q.g_v; cnt = P * (W / 2); }
-    else if (n == "ha") { src = q.ha; cnt = P * m->cfg.h_alpha_size; }
-    else if (n == "g_ha") { src = q.g_ha; cnt = P * m->cfg.h_alpha_size; }
-    else if (n == "hr") { src = q.hr; cnt = P * m->cfg.h_rgb_size; }
-    else if (n == "g_hr") { src = q.g_hr; cnt = P * m->cfg.h_rgb_size; }
-    else if (n == "theta") { src = q.theta; cnt = P * kThetaAll; }
-    else if (n == "g_theta") { src = q.g_theta; cnt = P * kThetaAll; }
-    else if (n == "enc") { src = q.enc; cnt = P * 64; }
-    else if (n == "at") { src = q.at; cnt = P * q.K * 2; }
-    else return -1;
-    if (cnt > max_floats) return -cnt;
-    if (hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) return -1;
-    return cnt;
-}
-// operand table entry by name: out[4] = {w_off, b_off, kc, nt}
-CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
-    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
-    ParamLayout L = build_layout(*cfg);
-    PackPlan P = build_pack_plan(*cfg, L);
-    const NetTab& T = P.tab;
-    const SubL* s = nullptr;
-    std::string n = name;
-    if (n == "trunk") s = &T.trunk[index]; else if (n == "skipseg") s = &T.skipseg; else if (n == "ha") s = &T.ha;
-    else if (n == "ft") s = &T.ft; else if (n == "vf") s = &T.vf; else if (n == "vd") s = &T.vd; else if (n == "hr") s = &T.hr;
-    else if (n == "fr") s = &T.fr; else if (n == "fa") s = &T.fa; else if (n == "bt_fr") s = &T.bt_fr;
-    else if (n == "bt_fa") s = &T.bt_fa; else if (n == "bt_hr") s = &T.bt_hr; else if (n == "bt_vf") s = &T.bt_vf;
-    else if (n == "bt_ft") s = &T.bt_ft; else if (n == "bt_ha") s = &T.bt_ha; else if (n == "bt_trunk") s = &T.bt_trunk[index];
-    if (!s) return CFNERF_E_INVALID;
-    out[0] = s->w_off; out[1] = s->b_off; out[2] = s->kc; out[3] = s->nt;
-    return CFNERF_OK;
-}
-}
-
 // ---- train-step entry points: implemented in cfnerf_bwd.hip -------------------------------------

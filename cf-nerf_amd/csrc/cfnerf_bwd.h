@@ -14,9 +14,9 @@ struct TailArgs {
     const float *d_rgb, *d_depth, *d_ent;
     int64_t N, P;
     int32_t S, K, flags;
-    int32_t ksplit;                                       // waves per ray: wave (ray, part) handles latents [part*Kp, (part+1)*Kp)
-    int32_t merge;                                        // ksplit 2 or 4: a ray's parts share a workgroup and add their g_theta rows in LDS: ONE part leaves
-    float *g_theta, *gms_partials;                        // [ksplit][P,128] partial theta gradients (summed by bwd_data's loader), [N*ksplit, 8]
+    int32_t ksplit;                                       // waves per ray (1, 2 or 4 = tail_parts): wave (ray, part) handles latents [part*Kp, (part+1)*Kp);
+                                                          // the parts of a ray are waves of ONE workgroup and add their g_theta rows in LDS
+    float *g_theta, *gms_partials;                        // [P,128] theta gradients (one row per point), [N*ksplit, 8]
 };
 
 struct BwdArgs {
@@ -24,8 +24,7 @@ struct BwdArgs {
     const void* wp16;                                     // split-bf16 operand copies (bf16x3 mode)
     int64_t P;
     int32_t n_wg, nb;
-    const float* g_theta;                                 // [g_parts][P,128]   input: partial sums from the tail kernel
-    int32_t g_parts;
+    const float* g_theta;                                 // [P,128]   input: d loss / d theta from the tail kernel (or flows_bwd)
     float *g_hr, *g_ha, *g_v, *g_feat, *g_h;              // outputs: pre-activation gradients, row-major per point
     const uint32_t* mbits;                                // [D+1][tiles][W/32][64] ReLU masks (fragment-ordered bit words)
     int64_t n_tiles; int32_t S;                           // same tiling as the forward: tile = ray * chunks_per_ray + chunk

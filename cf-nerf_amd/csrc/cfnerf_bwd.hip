@@ -17,6 +17,7 @@
 #include "cfnerf_kernels.h"
 #include "cfnerf_model.h"
 #include "cfnerf_bwd.h"
+#include "cfnerf_dwplan.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -323,11 +324,7 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
         float* lrow = lds_dst + rbase * ld;
         const int voff = (rbase * gld + col) * 4;
         const uint32_t mb = e.mb[j];
-#ifdef CFN_CSUM_PK        // (A/B builds, round 4) the column sum of a row pair as ONE packed fp32 add
-        f32x2 cs2; cs2[0] = 0.f; cs2[1] = 0.f;
-#else
         float csum = 0.f;
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -340,16 +337,8 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, col, v0, v1);
                 slab_store(sink, voff, rr * gld * 4, v0);
                 slab_store(sink, voff, (rr + 1) * gld * 4, v1);
-#ifdef CFN_CSUM_PK
-                f32x2 v2; v2[0] = v0; v2[1] = v1;
-                cs2 += v2;
-#else
                 csum += v0; csum += v1;
-#endif
             }
-#ifdef CFN_CSUM_PK
-        float csum = cs2[0] + cs2[1];
-#endif
         csum += __shfl_xor(csum, 32, 64);
         if (lane < 32) dbp[col] = e.db[j] + csum;    // this (workgroup, column) is owned by exactly one lane: no atomics
     }
@@ -383,11 +372,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
     // neighbour's MFMAs cover the constant-cache round trips and the ~650 v_readlane of the by-value scheme were the larger cost
     // (backward-data 1.166 -> 1.159 ms at W = 256); with ONE workgroup per CU (W > 256: one wave per SIMD, nothing covers a scalar
     // load) fetching per phase was 0.7 % SLOWER (2.215 -> 2.233 ms at W = 512), so the wide kernels keep the arguments by value.
-#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3 at every width: 222 spilt SGPRs at W = 256)
-    constexpr bool kKargMem = false;
-#else
     constexpr bool kKargMem = W <= 256;
-#endif
 #define CFN_KARGS const CFN_KCONST BwdKargs* kq_ = kernarg_fresh<BwdKargs, kKargMem>(); \
                   auto& A = karg_pick<kKargMem>::get(kq_->A, A_); auto& T = karg_pick<kKargMem>::get(kq_->T, T_)
 #define CFN_FRESH(x) sgpr_fresh_if<kKargMem>(x)
@@ -425,13 +410,8 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
         //      kGthB pieces.
         {
             constexpr int kGthN = kTileM * (kThetaAll / 4) / kThreads;
-#ifdef CFN_GTH_BATCH       // (A/B builds)
-            constexpr int kGthB = (W <= 256) ? kGthN : CFN_GTH_BATCH;
-#else
             constexpr int kGthB = (W <= 256) ? kGthN : 1;
-#endif
-            const float* const gth = A.g_theta;
-            const int parts = A.g_parts;
+            const float* const gth = A.g_theta;                 // ONE row per point: a ray's k-parts meet in LDS inside the tail kernel
 #pragma unroll
             for (int b0 = 0; b0 < kGthN; b0 += kGthB) {
                 f32x4 gv[kGthB];
@@ -440,24 +420,6 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
                     const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
                     gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
                     if (row < rows_valid) gv[i] = *reinterpret_cast<const f32x4*>(gth + (p0 + row) * kThetaAll + q * 4);
-                }
-                if (parts > 1) {                                   // partial sums of the tail kernel's k-parts, fixed order;
-                    for (int part = 1; part < parts; ++part) {     // the total goes back to part 0: the theta-head dW jobs read it
-                        f32x4 pv[kGthB];
-#pragma unroll
-                        for (int i = 0; i < kGthB; ++i) {
-                            const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
-                            pv[i][0] = pv[i][1] = pv[i][2] = pv[i][3] = 0.f;
-                            if (row < rows_valid) pv[i] = *reinterpret_cast<const f32x4*>(gth + ((size_t)part * P + p0 + row) * kThetaAll + q * 4);
-                        }
-#pragma unroll
-                        for (int i = 0; i < kGthB; ++i) gv[i] += pv[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < kGthB; ++i) {
-                        const int idx = tid + (b0 + i) * kThreads, row = idx >> 5, q = idx & 31;
-                        if (row < rows_valid) *reinterpret_cast<f32x4*>(const_cast<float*>(gth) + (p0 + row) * kThetaAll + q * 4) = gv[i];
-                    }
                 }
 #pragma unroll
                 for (int i = 0; i < kGthB; ++i) {
@@ -544,14 +506,10 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             __syncthreads();
         }
         // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
-#ifdef CFN_NO_BPRE      // (A/B builds)
-        constexpr bool kBPre = false;
-#else
         // the next layer's first weight fragments cross L2 under this layer's epilogue: -7 .. -13 us per launch at W = 256 on one box, +-0 on
         // another (the co-resident workgroup already covers most of that latency); at W = 512 the 16 extra registers cost +25 us, so the wide
         // kernels fetch them at the top of the k-loop as before.  (The same in the forward's trunk: +-0 on both boxes, not kept.)
         constexpr bool kBPre = PREC == PREC_F32 && W <= 256;
-#endif
         f32x4 bpre[NTW];
         if (kBPre) b_prefetch<NTW>(kload(T.bt_trunk[D - 1]), wave, kWaves, wp, bpre);
         for (int l = D - 1; l >= 1; --l) {
@@ -613,7 +571,6 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 //      the range and columns past the matrix come back as zeros from the hardware bounds check, the per-lane offsets are
 //      set up once and a stage advances ONE scalar offset - no per-stage address arithmetic on the vector pipe, which on
 //      this chip would come straight out of the MFMA issue slots.
-constexpr int kDwRows = 32;                   // points per LDS stage
 constexpr int kDwThreads = 512;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // a function's arguments arrive in VECTOR registers: tell the compiler they are wave-uniform, or every buffer load built
@@ -1151,188 +1108,6 @@ int cfnerf::ensure_bwd_plan(cfnerf_model* m) {
     return 0;
 }
 
-// one weight-gradient job -> tiles: 256 x 256 ("big" kernel) when the job is at least 128 x 128; else ("small" kernel)
-// tiles of (32 GN) x (32 GK WK), GN GK = 8 waves, with the wave arrangement picked from the job's shape
-static void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const float* dY, int ldY, int Nread, int N, const float* X,
-                    int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col, int row_f = 0) {
-    const bool is_big = N >= 128 && Kvalid >= 128;
-    int gk = 0, wk = 0;
-    if (!is_big) {          // wave arrangement GN x GK (GN GK = 8) from the job's K; a tile stages at most 128 + 64 or 64 + 128 columns
-        wk = 1;
-        gk = Kvalid <= 32 ? 1 : Kvalid <= 64 ? 2 : 4;
-    }
-    const int tn = is_big ? 256 : std::min(32 * (8 / gk), 128), tk = is_big ? 256 : 32 * gk;
-    for (int n0 = 0; n0 < N; n0 += tn)
-        for (int k0 = 0; k0 < Kvalid; k0 += tk) {
-            DwTile t{};
-            t.gk = is_big ? (N - n0 <= 128 ? 1 : 0) : gk; t.wk = wk;
-            t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
-            t.nseg = nseg;
-            for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
-            t.dst_ld = dst_ld; t.dst_col = dst_col; t.row_f = row_f;
-            (is_big ? big : small).push_back(t);
-        }
-}
-
-// every weight-gradient job of the network (dW[n][k] = sum_p dY[p][n] X[p][k]) as big / small tiles.  `q` supplies
-// the operand base pointers (geometry only depends on the configuration: the CPU test of the plan passes fakes).
-static void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash& q, int64_t P, std::vector<DwTile>& big,
-                          std::vector<DwTile>& small) {
-    const int W = c.netwidth, D = c.netdepth, HA = c.h_alpha_size, HR = c.h_rgb_size, F = c.n_flows;
-    const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = skip_layer(D);
-    char key[64];
-    const int one_row[1] = {0};
-    for (int l = 0; l < D; ++l) {
-        std::snprintf(key, sizeof key, "pts_linears.%d.weight", l);
-        const uint32_t dst[1] = {(uint32_t)L.off(key)};
-        const float* dY = q.g_h + (size_t)l * P * W;
-        if (l == 0) {
-            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0);
-        } else if (l - 1 == skip) {
-            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0);
-            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic);
-        } else {
-            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0);
-        }
-    }
-    const float* hlast = q.h + (size_t)(D - 1) * P * W;
-    { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0); }
-    { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0); }
-    {
-        const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
-        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
-        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
-    }
-    { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
-    {
-        const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
-        const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
-                                 (uint32_t)L.off("flows_rgb.amor_diag2.0.weight"), (uint32_t)L.off("flows_rgb.amor_b.weight")};
-        add_job(big, small, q.g_theta, kThetaAll, kThetaAll, 18 * kFlowsMax, q.hr, HR, HR, HR, 4, rows, dst, HR, 0, F);      // dY columns in the kernels' 4-step map
-    }
-    {
-        const int rows[3] = {0, F, 2 * F};
-        const uint32_t dst[3] = {(uint32_t)L.off("flows_alpha.amor_diag1.0.weight"), (uint32_t)L.off("flows_alpha.amor_diag2.0.weight"),
-                                 (uint32_t)L.off("flows_alpha.amor_b.weight")};
-        add_job(big, small, q.g_theta + kThetaRgb, kThetaAll, kThetaAll - kThetaRgb, 3 * kFlowsMax, q.ha, HA, HA, HA, 3, rows, dst, HA, 0, F);
-    }
-}
-
-// blocks of a launch: tile t contributes t.nsplit blocks, each with an equal share of the points (rounded to whole LDS
-// stages).  Slots [0, used splits of its tile) of a tensor's partials are exactly the ones a launch writes.
-static void make_blocks(std::vector<DwBlock>& blocks, std::vector<DwTile>& tiles, int64_t P, int round_to, int only_arr = -1) {
-    const size_t first = blocks.size();
-    for (int t = 0; t < (int)tiles.size(); ++t) {
-        if (only_arr >= 0 && tiles[t].gk != only_arr) continue;
-        const int nsplit = std::max(1, tiles[t].nsplit);
-        int64_t chunk = (P + nsplit - 1) / nsplit;
-        chunk = (chunk + round_to - 1) / round_to * round_to;
-        int used = 0;
-        for (int s = 0; s < nsplit; ++s) {
-            const int64_t pb = (int64_t)s * chunk, pe = std::min<int64_t>(P, pb + chunk);
-            if (pb >= pe) continue;
-            DwBlock b; b.tile = t; b.split = used++; b.kslice = 0; b.pad_ = 0; b.pb = pb; b.pe = pe;
-            blocks.push_back(b);
-        }
-        tiles[t].nsplit = used;
-    }
-    // longest blocks first: the hardware dispatches in index order
-    std::stable_sort(blocks.begin() + first, blocks.end(), [](const DwBlock& a, const DwBlock& b) { return (a.pe - a.pb) > (b.pe - b.pb); });
-}
-
-// Split counts of the big tiles: one block per CU in total (every block of the launch has the same footprint, so the
-// hardware places exactly one per CU whatever the mix), points shared out so that every block takes about the same time:
-// a 1 x 8 block (N <= 128) issues half the MFMAs per stage of a 2 x 4 block but pays the same fixed cost per stage, ~0.59
-// of its time per point (measured), so it gets proportionally more points.
-static void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, int max_split) {
-    if (tiles.empty()) return;
-    auto cost = [](const DwTile& t) { return t.gk == 1 ? 0.59 : 1.0; };
-    double total = 0;
-    for (const DwTile& t : tiles) total += cost(t);
-    int cap = max_split;
-    while (cap > 1 && P / cap < 512) --cap;                  // at least 512 points per block
-    int used = 0;
-    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(n_cu * cost(t) / total))); used += t.nsplit; }
-    while (used < n_cu) {                                    // hand the remaining CUs to the tiles whose blocks are longest
-        DwTile* best = nullptr;
-        for (DwTile& t : tiles)
-            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
-        if (!best) break;
-        ++best->nsplit; ++used;
-    }
-}
-
-// Split counts of the small jobs.  The launch is HBM-bound (a block streams 32 x (a_ld + b_ld) floats per stage), two
-// workgroups fit a CU, and with a fixed 128 splits per tile the 10 tiles of the default network made 1280 blocks = 2.5
-// rounds of 512 slots: the last half round ran on a half-empty chip.  Instead the launch is ONE round - 2 n_cu blocks that
-// all start together - and a tile's share of them is proportional to the bytes it streams per point (+ a fixed per-stage
-// cost), so they also end together; fewer splits are fewer partial slots for the reduction to read, too.
-static int small_stage_cols(const DwTile& t) {
-    const int gk = t.gk, gn = 8 / gk, tn = std::min(32 * gn, 128), tk = 32 * gk;
-    return pad_to(std::min(tn, t.N - t.n0), 32) + pad_to(std::min(tk, t.K - t.k0), 32);
-}
-static void balance_small_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P) {
-    if (tiles.empty()) return;
-    int cap = kDwSlots;
-    while (cap > 1 && P / cap < 512) cap >>= 1;              // at least 512 points per block
-#ifdef CFN_DS_FIXED_SPLITS
-    for (DwTile& t : tiles) t.nsplit = cap;
-    return;
-#endif
-    auto cost = [](const DwTile& t) { return (double)(small_stage_cols(t) + 32); };
-    double total = 0;
-    for (const DwTile& t : tiles) total += cost(t);
-    const int slots = 2 * n_cu;
-    int used = 0;
-    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(slots * cost(t) / total))); used += t.nsplit; }
-    while (used < slots) {                                   // the remaining slots go to the tiles whose blocks are longest
-        DwTile* best = nullptr;
-        for (DwTile& t : tiles)
-            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
-        if (!best) break;
-        ++best->nsplit; ++used;
-    }
-}
-
-// The whole host-side plan of the weight-gradient launches for one workspace binding: tiles, per-tile splits, blocks
-// (2 x 4 tiles first, then the 1 x 8 tiles), small-job blocks and the per-tensor slot counts of the reduction.
-// Returns nullptr or the reason it cannot be built.
-static const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, const Stash& q, int64_t P, int n_cu, DwHost& Hs,
-                                 int* n_blocks_wide, int* ns_max_out) {
-    Hs.tiles.clear(); Hs.tiles_small.clear(); Hs.blocks.clear(); Hs.blocks_small.clear(); Hs.segs.clear();
-    build_dw_jobs(c, L, q, P, Hs.tiles, Hs.tiles_small);
-    // split counts: big tiles ~1 block per CU in total, balanced by per-tile cost; small jobs a finer split (their
-    // blocks are short and run several per CU)
-    const int kMaxSplit = 64;
-    balance_big_splits(Hs.tiles, n_cu, P, kMaxSplit);
-    balance_small_splits(Hs.tiles_small, n_cu, P);
-    make_blocks(Hs.blocks, Hs.tiles, P, kDwRows);              // one launch: longest blocks first, whatever their arrangement
-    *n_blocks_wide = 0;
-    for (const DwBlock& b : Hs.blocks) *n_blocks_wide += Hs.tiles[b.tile].gk == 0;
-    make_blocks(Hs.blocks_small, Hs.tiles_small, P, kDwRows);
-    if ((int)Hs.tiles.size() > kMaxDwTiles || (int)Hs.tiles_small.size() > kMaxDwTiles || (int)Hs.blocks.size() > kMaxDwBlocks ||
-        (int)Hs.blocks_small.size() > kMaxDwBlocks)
-        return "weight-gradient plan exceeds the descriptor capacity";
-    // per-tensor split counts for the reduction (biases / dead tensors: 0 slots).  The tiles of one tensor may use
-    // different counts (a big and a small tile of the skip / views layer; tiles that got a spare CU): the tensor is
-    // reduced over the largest, so the slots some tile never writes must read as zero - the caller clears them when
-    // the plan is (re)built, never on the steady path, where every launch rewrites exactly the slots it wrote before.
-    int ns_max = 1;
-    for (const ParamEntry& e : L.e) { RedSeg r{}; r.begin = (uint32_t)e.off; r.nsplit = 0; r.early = 0; Hs.segs.push_back(r); }
-    auto mark = [&](const std::vector<DwTile>& tv, bool big) {
-        for (const DwTile& t : tv)
-            for (int g = 0; g < t.nseg; ++g)
-                for (RedSeg& r : Hs.segs)
-                    if (r.begin == t.seg_dst[g]) {
-                        if (r.nsplit == 0) r.early = big ? 1 : 0; else if (!big) r.early = 0;
-                        r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit);
-                    }
-    };
-    mark(Hs.tiles, true); mark(Hs.tiles_small, false);
-    *ns_max_out = ns_max;
-    return nullptr;
-}
-
 // Which kernel writes a tensor's gradient, and when it is final:
 //   biases (reduce_bias, right after bwd_data) and the base Gaussians (reduce_gms, right after the tail): nsplit = -1, the
 //   weight reduction skips them; dead tensors: zeros, written with the early phase; a weight fed only by big tiles: early.
@@ -1433,12 +1208,10 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         ta.raw = q.raw; ta.theta = q.theta; ta.at = q.at; ta.z = q.z; ta.rays = q.rays; ta.eps = m->d_eps; ta.flat = m->flat;
         ta.d_rgb = d_out; ta.d_depth = d_depth_map; ta.d_ent = d_entropy; ta.N = N; ta.P = P; ta.S = q.S; ta.K = q.K; ta.flags = q.flags;
         ta.g_theta = q.g_theta; ta.gms_partials = q.gms;
-        ksplit = tail_parts(N, q.K, std::min(m->n_cu, kMaxCu));      // (never more parts than the workspace was carved for)
-        ta.ksplit = ksplit;
-        ta.merge = (ksplit == 2 || ksplit == 4) ? 1 : 0;         // the parts of a ray are waves of one 4-wave workgroup: summed in LDS
+        ksplit = tail_parts(N, q.K, std::min(m->n_cu, kMaxCu));      // 1, 2 or 4: the parts of a ray are waves of ONE 4-wave workgroup and
+        ta.ksplit = ksplit;                                          // meet in LDS, so ONE g_theta row per point leaves the kernel
         gms_rows = N * ksplit;
         BHIP(launch_tail_bwd(ta, N, ksplit, st));
-        if (ta.merge) ksplit = 1;                                // ... and backward-data sees ONE g_theta part
     } else {
         unsigned grid = 0;
         BHIP(launch_flows_bwd(q.raw, q.theta, m->d_eps, m->flat, d_out, d_entropy, P, q.K, q.g_theta, q.gms, &grid, st));
@@ -1451,7 +1224,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
     // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
     BwdArgs ba{};                                              // (q.dbp needs no memset: every launched workgroup starts its row on its first tile)
     ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
-    ba.g_theta = q.g_theta; ba.g_parts = ksplit; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
+    ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;      // (points: ONE "ray" of S = P samples)
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;
     int grid_bd = 0;
@@ -1557,66 +1330,3 @@ int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float* grad_flat
 }
 
 }  // extern "C"
-
-// ---- debug / test helper (not part of include/cfnerf.h): the weight-gradient tile plan of a configuration, for the
-// CPU test that every weight element is covered exactly once.  16 int32 per tile:
-// {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[0..3], dst_ld, dst_col, 0, 0} followed by 4 uint32 seg_dst in a second array.
-extern "C" CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
-    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
-    ParamLayout L = build_layout(*cfg);
-    Stash q;                                   // fake, distinct operand bases: only the geometry is reported
-    float* base = reinterpret_cast<float*>(uintptr_t(1) << 40);
-    const size_t step = size_t(1) << 36;
-    float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
-    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
-    std::vector<DwTile> big, small;
-    build_dw_jobs(*cfg, L, q, P, big, small);
-    for (float** pp : ptrs) *pp = nullptr;
-    int n = 0;
-    for (int pass = 0; pass < 2; ++pass)
-        for (const DwTile& t : (pass == 0 ? big : small)) {
-            if (n >= max_tiles) return -n;
-            int32_t* o = tiles_out + 16 * n;
-            o[0] = pass == 0; o[1] = t.n0; o[2] = t.k0; o[3] = t.N; o[4] = t.K; o[5] = t.gk; o[6] = t.wk; o[7] = t.nseg;
-            for (int g = 0; g < 4; ++g) { o[8 + g] = t.seg_row[g]; segdst_out[4 * n + g] = t.seg_dst[g]; }
-            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = t.row_f; o[15] = 0;
-            ++n;
-        }
-    return n;
-}
-
-// the blocks of that plan for a given point count and CU count: 5 int64 per block {kind (0: 2 x 4, 1: 1 x 8, 2: small job), tile, split,
-// pb, pe}; tile indices refer to the order cfnerf_debug_dw_plan reports (big tiles, then small tiles); plus per tile its nsplit and, per
-// parameter tensor, the slot count of the reduction.
-extern "C" CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
-                                      int32_t* seg_nsplit, int max_segs) {
-    if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
-    ParamLayout L = build_layout(*cfg);
-    Stash q;
-    float* base = reinterpret_cast<float*>(uintptr_t(1) << 40);
-    const size_t step = size_t(1) << 36;
-    float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
-    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
-    DwHost H;
-    int n_wide = 0, ns_max = 0;
-    const char* why = build_dw_plan(*cfg, L, q, P, n_cu, H, &n_wide, &ns_max);
-    for (float** pp : ptrs) *pp = nullptr;
-    if (why) return CFNERF_E_UNSUPPORTED;
-    const int nb = (int)(H.blocks.size() + H.blocks_small.size());
-    if (nb > max_blocks || (int)L.e.size() > max_segs) return -nb;
-    int n = 0;
-    for (size_t i = 0; i < H.blocks.size(); ++i, ++n) {
-        const DwBlock& b = H.blocks[i];
-        int64_t* o = blocks_out + 5 * n;
-        o[0] = H.tiles[b.tile].gk == 1 ? 1 : 0; o[1] = b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
-    }
-    for (const DwBlock& b : H.blocks_small) {
-        int64_t* o = blocks_out + 5 * n++;
-        o[0] = 2; o[1] = (int64_t)H.tiles.size() + b.tile; o[2] = b.split; o[3] = b.pb; o[4] = b.pe;
-    }
-    int t = 0;
-    for (const DwTile& x : H.tiles) tile_nsplit[t++] = x.nsplit * (x.gk == 1 ? -1 : 1);     // sign: wave arrangement
-    for (const DwTile& x : H.tiles_small) tile_nsplit[t++] = x.nsplit;
-    for (size_t i = 0; i < H.segs.size(); ++i) seg_nsplit[i] = H.segs[i].nsplit;
-    return n;
-}

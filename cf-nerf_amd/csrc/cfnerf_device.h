@@ -119,13 +119,10 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][NTW]) {
 }
 
 // 16*NV MFMAs of one k-chunk (8 k values): a0/a1 = A fragments of the two row tiles, b[j] = B fragments
+// wave priorities: low inside the MFMA loops, raised in the epilogues (+1 % over none; the inverse pair +0.5 %: profiles/EXPERIMENTS.md)
 #define CFN_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#ifndef CFN_MMA_PRIO
 #define CFN_MMA_PRIO 0
-#endif
-#ifndef CFN_EPI_PRIO
 #define CFN_EPI_PRIO 2
-#endif
 template <int NTW, int NV>
 __device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NTW], const f32x4 a0, const f32x4 a1, const f32x4 (&b)[NTW]) {
 #pragma unroll
@@ -453,11 +450,7 @@ __device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t r, int voff_by
 // ragged tile fall outside the descriptor.  fp32 tiles only (the split-bf16 tiles hold hi / lo planes).  Used by the train forward
 // (-27 us at C2, -25 us at W = 512).  Backward-data keeps its element stores: the same scheme there measured -4 us at W = 256 and
 // +18 us at W = 512, and its last copy-out of a tile would need one more barrier in front of the next tile's first LDS write.
-#ifdef CFN_STASH_FROM_REGS      // (A/B builds: the round-2 scheme, fragment elements as dwords)
-constexpr bool kStashFromLds = false;
-#else
 constexpr bool kStashFromLds = true;
-#endif
 template <int WIDTH, int NTHR>
 __device__ __forceinline__ void stash_rows(const float* lds, int ld, float* __restrict__ gdst, int rows_valid) {
     constexpr int QPR = WIDTH / 4, TOTAL = kTileM * QPR;              // 16-byte pieces per row / per tile
@@ -524,17 +517,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 if (ACT == ACT_RELU) { v0 = relu_f(v0); v1 = relu_f(v1); }
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, lcol, v0, v1);
                 if (STASH) { slab_store(sink, voff, rr * gld * 4, v0); slab_store(sink, voff, (rr + 1) * gld * 4, v1); }
-#ifdef CFN_MASK_PKADD     // (A/B builds, round 4) the two "0 - v" of a row pair as ONE packed fp32 subtract: the sign of +0 - v is set iff v > 0
-                if (WANT_BITS) {
-                    f32x2 v2; v2[0] = v0; v2[1] = v1;
-                    f32x2 z2; z2[0] = 0.f; z2[1] = 0.f;
-                    const f32x2 n2 = z2 - v2;
-                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(n2[0]), 31);
-                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(n2[1]), 31);
-                }
-#else
                 if (WANT_BITS) { bits = relu_bit_push(bits, v0); bits = relu_bit_push(bits, v1); }
-#endif
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
         // backward-data kernel's output fragment has: it replaces 32 float loads per lane there
@@ -629,11 +612,7 @@ __device__ __forceinline__ float wave_scan_add_rev(float v) {
 // no LDS round trip).  __shfl_* compile to ds_bpermute_b32 - an LDS instruction with ~100 cycles of latency - and a scan is a chain
 // of six of them; the gfx9 DPP scan is row_shr:1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 to carry the
 // row totals on (the sequence LLVM's own wave scan uses).  A lane without a source keeps `identity` (bound_ctrl off).
-#ifdef CFN_NO_DPP           // (A/B builds: the shuffle forms everywhere)
-constexpr bool kUseDpp = false;
-#else
 constexpr bool kUseDpp = true;
-#endif
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov(float identity, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));

@@ -83,12 +83,6 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
     }
 }
 
-#ifdef CFN_TIMESTAMP
-__device__ unsigned long long g_dbg[4096];     // [0,2048): per-WG start/end/placement; [2048,..): per-layer marks of WG 0 and WG grid/2
-extern "C" CFNERF_API int cfnerf_debug_read_dbg(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
-}
-#endif
 
 // the kernarg segment of fused_fwd_kernel as one struct (second argument at the first argument's size rounded up to its own alignment)
 struct FwdKargs { FwdArgs A; NetTab T; };
@@ -113,16 +107,10 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
     [[maybe_unused]] float* const comp = red + 16;             /* [comp_rows(K)][8]: r g b depth acc T disp _ */                          \
     [[maybe_unused]] const float* __restrict__ const wp = F(wp0);                                                                          \
     [[maybe_unused]] const __bf16* __restrict__ const wp16 = F(wp160)
-#ifdef CFN_KARG_REGS            // (A/B builds: the by-value scheme of rounds 1-3: 289 spilt SGPRs in the W = 256 train variant)
-    const FwdArgs& A = A_; const NetTab& T = T_;
-#define CFN_KEEP(x) (x)
-#define CFN_PHASE_ARGS CFN_PHASE_LOCALS(CFN_KEEP)
-#else
     (void)A_; (void)T_;
 #define CFN_KARGS const CFN_KCONST FwdKargs* kq_ = kernarg_fresh<FwdKargs>(); const CFN_KCONST FwdArgs& A = kq_->A; const CFN_KCONST NetTab& T = kq_->T
 #define CFN_PHASE_ARGS CFN_KARGS; CFN_PHASE_LOCALS(sgpr_fresh)
     CFN_KARGS;
-#endif
     using C = FwdCfg<W>;
     constexpr int LD = C::LD;
     constexpr int kWv = C::NWV, kThr = C::NTHR;     // waves / threads of this width's workgroup
@@ -145,20 +133,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
     const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
     const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
 
-#ifdef CFN_TIMESTAMP
-    const unsigned long long t_start = wall_clock64();
-    int dbg_n = 0;
-    const int dbg_sel = (blockIdx.x == 0) ? 0 : (blockIdx.x == (gridDim.x >> 1)) ? 1 : -1;
-#define CFN_MARK() do { if (dbg_sel >= 0 && tid == 0 && dbg_n < 700) g_dbg[2048 + dbg_sel * 700 + dbg_n++] = wall_clock64(); } while (0)
-#ifdef CFN_TIMESTAMP_FINE
-#define CFN_MARK2() CFN_MARK()
-#else
-#define CFN_MARK2() ((void)0)
-#endif
-#else
-#define CFN_MARK() ((void)0)
-#define CFN_MARK2() ((void)0)
-#endif
     for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         float ro[3], rd[3], nearv = 0.f, farv = 1.f, dnorm = 0.f;
         CFN_PHASE_ARGS;
@@ -232,8 +206,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
                 __syncthreads();
             }
-
-            CFN_MARK();                              // sampling done
             // Biases are fetched ONE PHASE AHEAD of the accumulator initialisation that needs them (the accumulators must
             // hold them before a layer's first MFMA, so a fetch at the top of the layer is an exposed L2 round trip per layer):
             // layer 0's rides under the encoding, layer l+1's under layer l's MFMAs, and so on down the heads.
@@ -261,11 +233,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             // slot was rewritten every tile and every one of those writes went through L2 to memory - 33 MB of WRITE_SIZE per C2
             // launch against 82 KB of outputs (profiles/r02_traffic.json).  (The split-bf16 eval kernel has no registers to spare and the
             // train variants want the tile in the stash anyway: they park it in memory as before.)
-#ifdef CFN_PARK_MEM      // (A/B builds: the round-2 scheme)
-            constexpr bool kParkRegs = false;
-#else
             constexpr bool kParkRegs = MODE == 0 && !TRAIN && PREC == PREC_F32;
-#endif
             constexpr int kParkN = kTileM * 16 / kThr;
             f32x4 park[kParkRegs ? kParkN : 1];
             float* enc_park = (MODE == 0 && !kParkRegs) ? (A.st_enc != nullptr ? A.st_enc + p0 * 64 : A.enc_scratch + (size_t)blockIdx.x * (kTileM * 64)) : nullptr;
@@ -292,32 +260,20 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
             }
             __syncthreads();
-
-            CFN_MARK();                              // encoding done
             // ---- 3. trunk: D x (Linear + ReLU), skip concat after layer D/2   (MOD:168-172)
-#ifdef CFN_ACC_EARLY     // (A/B builds, round 4) the accumulators take the next layer's bias BEFORE the stash copy-out of this layer is issued
-            f32x16 acc[2][C::NTW];
-            acc_init(acc, bias_n);
-#endif
             for (int l = 0; l < Dn; ++l) {
                 CFN_PHASE_ARGS;
-#ifndef CFN_ACC_EARLY
                 f32x16 acc[2][C::NTW];
-#endif
                 const SubL tl_nn = kload((l + 2 < Dn) ? T.trunk[l + 2] : T.ft);                 // (in flight under this layer's MFMAs)
-#ifndef CFN_ACC_EARLY
                 acc_init(acc, bias_n);
                 // the accumulators take the bias fetched a layer ago (its wait also drains the previous layer's stash stores: one counter);
                 // only THEN is the next layer's bias requested - hoisted above that wait it would expose an L2 round trip per layer
                 asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][C::NTW - 1][0]) : "memory");
-#endif
                 load_bias<C::NTW>(tl_nxt, wave, kWv, wp, bias_n);                               // next layer's / the feature head's
-                CFN_MARK();                          // MFMA phase of layer l starts
                 mma_any<C::NTW, PREC, 2>(acc, tl_cur, wave, kWv, wp, wp16, act, LD);
                 // (all four dwords of the prefetched entry stay live to here: the fp32 kernels never read w16_off, and a dead destination
                 // register of an s_load in flight gets reused at once - a write-after-write wait on the load that was meant to be hidden)
                 asm volatile("" :: "s"(tl_nn.w16_off));
-                CFN_MARK();                          // ... ends for wave 0
                 if (l >= 1 && l - 1 == skip_l) {
                     __syncthreads();                 // every wave is done reading h_{l-1}
                     if (kParkRegs) {                 // act[:, 0:64) <- gamma(p) again, from the registers it was kept in
@@ -343,19 +299,12 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     mma_any<C::NTW, PREC, 2>(acc, tl_skip, wave, kWv, wp, wp16, act, LD);
                 }
                 __syncthreads();
-                CFN_MARK2();                         // all waves done with the MFMAs of this layer
                 float* st = (te_st0 != nullptr) ? te_st0 + (size_t)l * te_st_step : nullptr;
                 uint32_t* mb = (te_mb0 != nullptr) ? te_mb0 + (size_t)l * te_mb_step : nullptr;
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
                 store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
-                CFN_MARK2();                         // wave 0 done storing
                 __syncthreads();
-#ifdef CFN_ACC_EARLY
-                acc_init(acc, bias_n);               // (the next layer's / the feature head's; fetched at this layer's top)
-                asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][C::NTW - 1][0]) : "memory");
-#endif
                 if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
-                CFN_MARK();                          // epilogue + barrier done
                 tl_cur = tl_nxt; tl_nxt = tl_nn;
             }
             const SubL tl_ft = tl_cur;               // after the last layer: the feature head's entry
@@ -366,19 +315,13 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
             float bias_v[C::NTV];                    // views-layer bias, in flight during the heads
             {
                 CFN_PHASE_ARGS;
-#ifdef CFN_ACC_EARLY
-                auto& accF = acc;
-#else
                 f32x16 accF[2][C::NTW];
-#endif
                 f32x16 accA[2][1];
                 const SubL s_vf = kload(T.vf), s_ha = kload(T.ha);
                 float* const st_ha = A.st_ha;
                 float* const st_feat = A.st_feat;
                 fetched_together(s_vf.w_off, s_ha.w_off, st_ha, st_feat);
-#ifndef CFN_ACC_EARLY
                 acc_init(accF, bias_n);
-#endif
                 acc_zero(accA);
                 load_bias<C::NTV>(s_vf, wave, kWv, wp, bias_v);
                 mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
@@ -431,7 +374,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 __syncthreads();
                 if (kRows && st_feat != nullptr) stash_rows<W, kThr>(act, LD, st_feat + p0 * W, rows_valid);
             }
-            CFN_MARK();                              // heads done
             // ---- 5. views layer: v = relu(V [feature | gamma(d)])   (MOD:177-181)
             float bias_h[1];                         // h_rgb bias, in flight during the views layer
             {
@@ -463,7 +405,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 __syncthreads();
                 if (kRows && st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, st_v + p0 * (W / 2), rows_valid);
             }
-            CFN_MARK();                              // views done
             // ---- 6. h_rgb = R v   (MOD:182)  -> act[:, W/2 : W/2 + HR)
             {
                 CFN_PHASE_ARGS;
@@ -478,7 +419,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                                          st_hr ? st_hr + p0 * HR : nullptr, HR, rows_valid);
                 __syncthreads();
             }
-            CFN_MARK();                              // h_rgb done
             // ---- 7. amortised flow parameters (MOD:366-383), once per point (the reference recomputes
             //         them K times on duplicated rows, MOD:210-217): theta -> act[:, 0:128)
             {
@@ -520,7 +460,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 }
                 __syncthreads();
             }
-            CFN_MARK();                              // theta done
             // ---- 8. flows + composite: lane = sample (row), waves stride over the K latent samples
             {
                 CFN_PHASE_ARGS;
@@ -602,7 +541,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 else flow_phase(std::false_type{});
             }
             __syncthreads();
-            CFN_MARK();                              // flows + composite done
         }  // chunks
 
         {   // ---- 9. the ray's outputs
@@ -649,14 +587,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
         __syncthreads();
     }  // units
 
-#ifdef CFN_TIMESTAMP
-    if (tid == 0 && blockIdx.x < 1024) {
-        g_dbg[blockIdx.x * 4 + 0] = t_start;
-        g_dbg[blockIdx.x * 4 + 1] = wall_clock64();
-        g_dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((15 << 11) | 4);      // HW_ID[15:0]
-        g_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // XCC_ID
-    }
-#endif
     if (TRAIN) {
       CFN_PHASE_ARGS;
       if (A.ent_partials != nullptr) {
@@ -677,7 +607,6 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
 #undef CFN_PHASE_ARGS
 #undef CFN_PHASE_LOCALS
 #undef CFN_KARGS
-#undef CFN_KEEP
 }
 
 // loss_entropy = mean(base_a) - mean(ld_a) + mean(base_rgb) - mean(ld_rgb)      (MOD:268,283,286)
@@ -1191,9 +1120,6 @@ static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
         if (e != hipSuccess) return e;
         per_cu = std::min(per_cu, max_blocks_per_cu(fn, fwd_lds_bytes(W, ha, 16), FwdCfg<W>::NTHR));
     }
-#ifdef CFN_FWD_MAX_PER_CU
-    if (per_cu > CFN_FWD_MAX_PER_CU) per_cu = CFN_FWD_MAX_PER_CU;
-#endif
     *per_cu_out = std::max(1, per_cu);
     return hipSuccess;
 }

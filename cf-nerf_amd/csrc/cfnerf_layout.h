@@ -97,11 +97,7 @@ inline ParamLayout build_layout(const cfnerf_cfg& c) {
     return L;
 }
 
-#if defined(__HIPCC__)
-#define CFN_HD_EARLY __host__ __device__
-#else
-#define CFN_HD_EARLY
-#endif
+#define CFN_HD_EARLY __host__ __device__      // (every translation unit of the library is compiled by hipcc)
 // One packed GEMM operand: B fragments of an [N_out x K_red] matrix for v_mfma_f32_32x32x2_f32.
 //   packed[((nt * kc_count + kc) * 64 + lane) * 4 + c] = M[nt*32 + (lane & 31)][kc*8 + 4*(lane >> 5) + c]
 // (zero outside the valid range).  A float4 per lane feeds 4 MFMAs; the A operand uses the same
@@ -172,11 +168,7 @@ struct PackDesc {
     uint32_t kc16;       // k16-chunk count of the bf16 copy
 };
 
-#if defined(__HIPCC__)
 #define CFN_HD __host__ __device__
-#else
-#define CFN_HD
-#endif
 // flat element `local` of piece `d`  ->  (source index in the flat buffer, destination index in the packed buffer)
 CFN_HD inline void pack_map(const PackDesc& d, uint32_t local, uint32_t* src, uint32_t* dst) {
     if (d.n_cols == 0) {

@@ -15,22 +15,20 @@ constexpr int kNumTimers = 5;   // 0 fwd, 1 bwd_tail, 2 bwd_data, 3 bwd_dw, 4 ad
 constexpr int kFwdRing = 64;    // event pairs kept for the forward launch (mean over the last n launches)
 constexpr int kDwSlots = 128;   // split-K slots of the weight-gradient partials (upper bound of any split count)
 constexpr int kMaxDwTiles = 256, kMaxDwBlocks = 16384;     // descriptor capacities carved out of the workspace
-constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over up to this many waves (partial g_theta buffers)
+constexpr int kTailParts = 4;   // the tail kernel splits a ray's K latents over up to this many waves of one workgroup (they meet in LDS)
+constexpr int kTailMinPerPart = 2;   // a second wave per SIMD pays down to 2 latents per part (32 before the parts of a ray met in LDS)
 // k-parts of the tail kernel for a batch: it runs ONE wave per SIMD, so a ray's latents are split over more waves only while all
 // waves still fit in one round (measured: a second round costs more than the shorter k-loops save); at most kTailParts, never more
-// than K / 2.  The workspace is carved for the CU count's upper bound (kMaxCu), the launch uses the device's own.
+// than K / 2; always a power of two (1, 2 or 4), so a ray's parts are waves of ONE 4-wave workgroup.
 // Round 4: the kernel fits 256 registers since it is built without the SLP vectoriser (cfnerf_tail.hip), so a SECOND wave per SIMD is
 // possible.  While the parts met in memory (a partial g_theta per part, summed by backward-data) it paid only with >= 32 latents per part;
-// since they meet in LDS (tail_bwd_kernel, `merge`) backward-data does not see them and the second wave pays down to 2 latents per
+// since they meet in LDS (tail_bwd_kernel) backward-data does not see them - ONE g_theta row per point - and the second wave pays down to 2 latents per
 // part: same-box A/B tail 57.8 -> 55.0 us (C2, K = 4), 93.4 -> 87.4 (C4, K = 16), 81.0 -> 76.5 (W512: four parts of 8), backward-data +-0.
 inline int tail_parts(int64_t n_rays, int k, int n_cu) {
     int parts = 1;
     while (parts < kTailParts && parts * 2 <= k) {
         const bool one_round = n_rays * parts * 2 <= (int64_t)n_cu * 4;
-#ifndef CFN_TAIL_MIN_PER_PART      // (A/B builds; 32 = the rule before the parts of a ray met in LDS)
-#define CFN_TAIL_MIN_PER_PART 2
-#endif
-        const bool second_wave = n_rays * parts * 2 <= (int64_t)n_cu * 8 && k / (parts * 2) >= CFN_TAIL_MIN_PER_PART;
+        const bool second_wave = n_rays * parts * 2 <= (int64_t)n_cu * 8 && k / (parts * 2) >= kTailMinPerPart;
         if (!one_round && !second_wave) break;
         parts *= 2;
     }
@@ -59,7 +57,7 @@ struct Stash {
     float *mbits = nullptr;  // [D+1][tiles][W/32][64] u32 ReLU mask words (fragment order)
     // ---- written by the backward (same row-major-per-point convention)
     float *gms = nullptr;       // [N*parts,8]    base-Gaussian gradient partials
-    float *g_theta = nullptr;   // [parts][P,128]  d loss / d theta (pre-tanh for the diagonal columns), one partial per k-part
+    float *g_theta = nullptr;   // [P,128]  d loss / d theta (pre-tanh for the diagonal columns)
     float *g_hr = nullptr;      // [P,HR]
     float *g_ha = nullptr;      // [P,HA]
     float *g_v = nullptr;       // [P,W/2]  pre-activation gradient of the views layer
@@ -107,7 +105,7 @@ struct Stash {
         take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
         take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
         take(&t->gms, (size_t)(std::max<int64_t>(n * kTailParts, tiles) + 8) * 8, 4);      // rays * k-parts (fused tail) or waves of points (flows_bwd)
-        take(&t->g_theta, (size_t)tail_parts(n, k, kMaxCu) * P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);      // one partial per k-part
+        take(&t->g_theta, (size_t)P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);      // ONE row per point whatever the k-parts
         take(&t->g_ha, (size_t)P * c.h_alpha_size, 4); take(&t->g_v, (size_t)P * (W / 2), 4);
         take(&t->g_feat, (size_t)P * W, 4); take(&t->g_h, (size_t)D * P * W, 4);
         take(&t->dbp, (size_t)n_wg * nb, 4);

@@ -162,13 +162,13 @@ void tail_bwd_kernel(const TailArgs A) {
     const int64_t unit = (int64_t)blockIdx.x * kWaves + wave;
     const int64_t ray_u = unit / A.ksplit;
     const int part = (int)(unit - ray_u * A.ksplit);
-    const bool merge = A.merge != 0;
+    static_assert(kWaves % kTailParts == 0 && (kTailParts & (kTailParts - 1)) == 0, "a ray's k-parts must be waves of one workgroup");
+    const bool merge = A.ksplit > 1;                       // (tail_parts: 1, 2 or 4 - the divisors of the workgroup's 4 waves)
     const bool live = ray_u < A.N;
     if (!live && !merge) return;                           // (merge: every wave of the workgroup keeps step with the barriers below)
     const int64_t ray = live ? ray_u : 0;                  // (a wave past the last ray addresses ray 0 and touches nothing)
     const int S = A.S, K = A.K;
     const int Kp = (K + A.ksplit - 1) / A.ksplit, k_lo = part * Kp, k_hi = min(K, k_lo + Kp);
-    float* __restrict__ g_theta_out = A.g_theta + (size_t)part * A.P * kThetaAll;
     const float* rr = A.rays + ray * 11;
     const float dnorm = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);
     const float cE = -((A.d_ent != nullptr) ? A.d_ent[0] : 0.f) / (float)((double)A.P * (double)K);
@@ -213,7 +213,7 @@ void tail_bwd_kernel(const TailArgs A) {
             q.Gd = (A.d_depth != nullptr) ? A.d_depth[ray * (int64_t)K + k] : 0.f;
             return q;
         };
-        KIn nx = fetch(k_lo);
+        KIn nx = fetch(min(k_lo, K - 1));                  // (K not a multiple of the parts: a last part may be empty - its prefetch stays in range)
         for (int k = k_lo; k < k_hi; ++k) {
             const KIn cur = nx;
             if (k + 1 < k_hi) nx = fetch(k + 1);
@@ -256,7 +256,7 @@ void tail_bwd_kernel(const TailArgs A) {
             __syncthreads();                               // (the rows are free again)
             if (part == 0 && valid) store_gtheta_row(A.g_theta + p * kThetaAll, th, gth);
         } else if (valid) {
-            store_gtheta_row(g_theta_out + p * kThetaAll, th, gth);
+            store_gtheta_row(A.g_theta + p * kThetaAll, th, gth);
         }
     }
     if (!live) return;

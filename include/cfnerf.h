@@ -38,9 +38,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-/* The library is built with -fvisibility=hidden: its dynamic symbol table holds the entry points declared in THIS header (plus
- * the test hooks of tests/cfnerf_debug.h, which are not part of the ABI) and nothing else - no C++ symbol, no helper.
- * tests/test_abi_cpu.py compares `nm -D --defined-only` of the library with the two headers. */
+/* The library is built with -fvisibility=hidden: its dynamic symbol table holds the entry points declared in THIS header and
+ * nothing else - no C++ symbol, no helper, no test hook (those live in a separate test library, tests/cfnerf_debug.h).
+ * tests/test_abi_cpu.py compares `nm -D --defined-only` of the library with this header. */
 #if defined(__GNUC__) || defined(__clang__)
 #define CFNERF_API __attribute__((visibility("default")))
 #else

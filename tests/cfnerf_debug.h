@@ -1,10 +1,13 @@
 /*
- * cfnerf_debug.h - TEST HOOKS exported by libcfnerf_hip.so next to the ABI of include/cfnerf.h.
+ * cfnerf_debug.h - TEST HOOKS, exported by a SEPARATE test library (tests/csrc/cfnerf_testhooks.hip ->
+ * cf-nerf_amd/build/libcfnerf_testhooks.so), not by the product: libcfnerf_hip.so exports include/cfnerf.h and nothing else
+ * (round 4 shipped these six symbols inside the product library).
  *
- * Not part of the drop-in boundary: nothing in cf-nerf_amd/ (the product's host side) calls them; they let tests/ read
- * internal state that the ABI deliberately hides - the packed operand layout, the weight-gradient plan, the activation
- * stash of the last CFNERF_F_STASH forward.  tests/test_abi_cpu.py holds the library's dynamic symbol table to exactly
- * the union of include/cfnerf.h and this header.
+ * Not part of the drop-in boundary: nothing in cf-nerf_amd/ (the product's host side) loads that library; the hooks let tests/
+ * read internal state that the ABI deliberately hides - the packed operand layout, the weight-gradient plan (host-side planners,
+ * header-only code shared with the product) and the activation stash of the last CFNERF_F_STASH forward (a copy out of the
+ * workspace of a handle the PRODUCT library created).  tests/test_abi_cpu.py holds the product library's dynamic symbol table to
+ * exactly include/cfnerf.h and the test library's to exactly this header.
  */
 #ifndef CFNERF_DEBUG_H
 #define CFNERF_DEBUG_H
@@ -30,10 +33,6 @@ CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
  * per parameter tensor the slot count of the reduction */
 CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
                                       int32_t* seg_nsplit, int max_segs);
-#ifdef CFN_TIMESTAMP
-/* (timeline builds, -DCFN_TIMESTAMP only) the s_memrealtime marks of the fused forward, tests/tools/wg_timeline.py */
-CFNERF_API int cfnerf_debug_read_dbg(unsigned long long* host, int n);
-#endif
 
 #ifdef __cplusplus
 }

@@ -675,6 +675,97 @@ def main():
     g19 = psnr_curve_fixture(R, tmp)
     out["g19_psnr_curve"] = g19
 
+    # ================= fixtures added in round 5 (own random streams) ==========================================================
+    # ---------------- G20: NON-DEFAULT positional encodings, --multires 6 --multires_views 2 (RUN:641-644, HLP:54-69): 39 + 15 input
+    #                  channels change the K dimension of layer 0, the skip block and the view block and the in-kernel encoder -------------
+    rng20 = np.random.default_rng(120)
+    cfg = O.OracleCfg(netwidth=64, K_samples=3, multires=6, multires_views=2)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 67, tmp, K_samples=3)
+    net = model.module
+    n = 10
+    rays, (H, W, focal) = fern_rays(rng20, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng20.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    t_rand = torch.tensor(rng20.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng20.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng20.standard_normal((3, 3)), dtype=torch.float32)
+    with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
+    nk, eps, beta1 = 3, 1e-05, 0.02
+    loss_nll = reference_kde_nll(rgbs, target, nk)
+    loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, _ = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., **kw_test)
+    x54 = torch.tensor(rng20.uniform(-1, 1, (12, cfg.input_ch + cfg.input_ch_views)), dtype=torch.float32)
+    with ExplicitRandom(normals=[ea, er]):
+        raw_x, ent_x = net(x54, False, False)
+    g20 = dict(seed=67, netwidth=64, K=3, multires=6, multires_views=2, input_ch=args.input_ch, input_ch_views=args.input_ch_views,
+               H=H, W=W, focal=focal, rays=rays_t, target=target, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, beta1=beta1, rgb_map=rgbs,
+               depth_map=depth, disp_map=disp, raw_first2=extras["raw"][:2], loss=loss.detach(), loss_nll=loss_nll.detach(),
+               loss_entropy=extras["loss_entropy"].mean().detach(), rgb_map_eval=rgbs_e, depth_map_eval=depth_e,
+               x54=x54, raw_x=raw_x.detach(), loss_entropy_x=ent_x.reshape(-1)[0].detach(),
+               **{"shape." + k[len("module."):]: np.array(v.shape) for k, v in model.state_dict().items()
+                  if k.endswith("pts_linears.0.weight") or k.endswith("pts_linears.5.weight") or k.endswith("views_linears.0.weight")})
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            g20["grad." + k[len("module."):]] = v.grad.clone()
+    out["g20_train_multires_6_2"] = g20
+
+    # ---------------- G21: the AUTHORS' RECIPE (train_NF.sh:1-19 + configs/africa_ds.txt): netwidth 512, h_alpha 64, h_rgb 64, K 32, no NDC.
+    #                  The build's W = 512 kernels use a different register / argument scheme from W <= 256; this pins them to the real
+    #                  reference: outputs, loss, and of every gradient its Frobenius norm, float64 sum and 64 sampled entries (the
+    #                  2.36 M-entry gradient itself would be 9 MB), plus one Adam step on the same samples --------------------------------
+    rng21 = np.random.default_rng(121)
+    cfg = O.OracleCfg(netwidth=512, K_samples=32, h_alpha_size=64, h_rgb_size=64)
+    args, kw_train, kw_test, model, p, optimizer = build_reference_model(R, cfg, 68, tmp, K_samples=32, no_ndc=True)
+    net = model.module
+    n = 4
+    rays, (H, W, focal) = fern_rays(rng21, n)
+    rays_t = torch.tensor(rays)
+    near, far = 1.2, 8.0
+    target = torch.tensor(rng21.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    t_rand = torch.tensor(rng21.uniform(0, 1, (n, 128)), dtype=torch.float32)
+    ea = torch.tensor(rng21.standard_normal((32, 1)), dtype=torch.float32)
+    er = torch.tensor(rng21.standard_normal((32, 3)), dtype=torch.float32)
+    with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+        rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=near, far=far, verbose=False, retraw=False, **kw_train)
+    nk, eps, beta1 = 32, 1e-05, 0.01
+    loss_nll = reference_kde_nll(rgbs, target, nk)
+    loss = loss_nll + beta1 * extras["loss_entropy"].mean()
+    optimizer.zero_grad()
+    loss.backward()
+    g21 = dict(seed=68, netwidth=512, K=32, h_alpha_size=64, h_rgb_size=64, H=H, W=W, focal=focal, near=near, far=far, ndc=0, rays=rays_t,
+               target=target, t_rand=t_rand, eps_alpha=ea, eps_rgb=er, beta1=beta1, rgb_map=rgbs, depth_map=depth, disp_map=disp,
+               raw_first1=extras["raw"][:1], loss=loss.detach(), loss_nll=loss_nll.detach(), loss_entropy=extras["loss_entropy"].mean().detach())
+    named = {k[len("module."):]: v for k, v in model.named_parameters()}
+    samples = {}
+    for k, v in named.items():
+        if v.grad is None:
+            continue
+        gf = v.grad.reshape(-1)
+        idx = np.sort(rng21.choice(gf.numel(), size=min(64, gf.numel()), replace=False))
+        samples[k] = torch.tensor(idx)
+        g21["gradidx." + k] = idx
+        g21["gradsample." + k] = gf[samples[k]].clone()
+        g21["gradnorm." + k] = gf.double().norm()
+        g21["gradsum." + k] = gf.double().sum()
+        g21["gradabsmax." + k] = gf.abs().max()
+    optimizer.step()
+    for k, idx in samples.items():
+        g21["adam1sample." + k] = named[k].detach().reshape(-1)[idx].clone()
+    sd = model.state_dict()
+    for k, v in p.items():
+        sd["module." + k] = v.clone()
+    model.load_state_dict(sd)
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, _ = R.render(H, W, focal, chunk=8192, rays=rays_t, near=near, far=far, **kw_test)
+    g21.update(rgb_map_eval=rgbs_e, depth_map_eval=depth_e)
+    out["g21_train_authors_recipe_w512"] = g21
+
     import hashlib
     import json
     argv = sys.argv[1:]

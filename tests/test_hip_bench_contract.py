@@ -98,8 +98,19 @@ def test_psnr_block_is_in_the_default_line():
     assert r["agree"] is True and set(r["max_abs_held_out_psnr_diff_db"]) == {"0", "40", "80", "120"}
     assert r["max_abs_held_out_psnr_diff_db"]["120"] <= r["tolerance_db_at_last_step"] <= 0.01
     assert r["reference_held_out_psnr_db"]["120"] > r["reference_held_out_psnr_db"]["0"] + 4.0
-    for k in ("alt_precision", "stress_w512", "alt_config", "cpu_baseline"):
+    for k in ("alt_precision", "stress_w512", "eval", "cpu_baseline"):
         assert k in d, k
+    assert "alt_config" not in d                                             # the parity-unpinned extension is opt-in (--extension) since round 5
+    # the other half of SURVEY 8(d)'s metric in the default line: eval-render throughput of the C2 batch and of config 5 (800 x 800, K 32)
+    e = d["eval"]
+    e2, e5 = e["config2_eval"], e["config5_full_image"]
+    assert e2["workload"].startswith("C2") and "mode=eval" in e2["workload"] and e2["unit"] == "rays/s"
+    assert abs(e2["value"] - 1024 / (e2["ms_per_step"] * 1e-3)) <= 1e-6 * e2["value"]
+    assert e2["fwd_launch_ms"] <= e2["ms_per_step"] * 1.02 and 0.4 < e2["roofline"]["frac"] < 1.0
+    assert e2["value"] > 2.0 * d["value"]                                   # eval = one of the step's three GEMM passes, and no stash
+    assert e5["workload"].startswith("C5") and "K=32" in e5["workload"] and e5["images"] >= 2
+    assert abs(e5["value"] - 640000 / e5["s_per_image"]) <= 1e-6 * e5["value"]
+    assert e5["fwd_launch_ms"] * 1e-3 <= e5["s_per_image"] * 1.02 and 0.4 < e5["roofline"]["frac"] < 1.0
 
 
 @pytest.mark.parametrize("argv,workload", [(("--config", "C4", "--steps", "4", "--warmup", "2"), "C4"),
@@ -148,6 +159,9 @@ def test_gpus_2_default_line_explains_itself():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0
     assert "config4_k16" in d and "alt_precision" in d
+    e = d["eval"]                                                           # eval render at N = 2: C2 rays per rank, config 5's rows tiled over the ranks
+    assert abs(e["config2_eval"]["value"] - 2 * 1024 / (e["config2_eval"]["ms_per_step"] * 1e-3)) <= 1e-6 * e["config2_eval"]["value"]
+    assert "rows 0..400 of 800" in e["config5_full_image"]["workload"] and e["config5_full_image"]["value"] > 0
 
 
 def test_k64_config_runs():

@@ -15,7 +15,8 @@ DEV = "cuda"
 
 def cfg_from(g):
     return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g.get("netdepth", 8)), n_flows=int(g.get("n_flows", 4)),
-                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)),
+                       multires=int(g.get("multires", 10)), multires_views=int(g.get("multires_views", 4)))
 
 
 def test_native_library_is_loaded():

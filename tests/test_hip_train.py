@@ -20,7 +20,7 @@ DEV = "cuda"
 # on a pre-activation smaller than that layer's activation error (util_hip.oracle_train_step_on_hip_masks).  Against
 # fixtures of the real reference - whose masks are the oracle's own - the fixture is corrected by the oracle's
 # gradient difference between the two mask sets, which is exactly the part of the function that changed.
-from util_hip import G_TIGHT, grad_close_tight, oracle_train_step_on_hip_masks
+from util_hip import G_TIGHT, fuzz_case, grad_close_tight, oracle_train_step_on_hip_masks
 
 
 def grad_close(g, ref, what):
@@ -46,7 +46,8 @@ def check_all_grads(net, grad, grads, what=""):
 
 def cfg_from(g):
     return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g.get("netdepth", 8)), n_flows=int(g.get("n_flows", 4)),
-                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)),
+                       multires=int(g.get("multires", 10)), multires_views=int(g.get("multires_views", 4)))
 
 
 @pytest.mark.parametrize("tag", ["w64_ndc", "w64_nondc_lindisp_wb", "w256_ndc"])
@@ -244,6 +245,139 @@ def test_train_step_wide_config_vs_reference_golden(golden):
         rgbs_e, _, depth_e, _ = cfnerf_amd.render(H, W, focal, rays=T(g["rays"]).to(DEV), near=0., far=1., **kw_test)
     close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
     close(depth_e, g["depth_map_eval"], what="depth_map_eval")
+
+
+def test_train_step_non_default_multires_vs_reference_golden(golden):
+    """G20: --multires 6 --multires_views 2 (RUN:641-644, HLP:54-69) through the REAL reference: 39 + 15 input channels change the K
+    dimension of layer 0, of the skip block and of the view block, and the in-kernel encoder.  The network on a [P, 54] input, render
+    outputs, loss, entropy, every parameter gradient, eval render."""
+    g = golden("g20_train_multires_6_2")
+    cfg = cfg_from(g)
+    assert (cfg.multires, cfg.multires_views) == (6, 2)
+    args, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]))
+    assert (args.input_ch, args.input_ch_views) == (int(g["input_ch"]), int(g["input_ch_views"])) == (39, 15)
+    net = model.module
+    for k in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight"):
+        assert list(net.view(k).shape) == list(g["shape." + k]), k
+    with torch.no_grad():
+        raw_x, ent_x = net(T(g["x54"]).to(DEV), False, False, eps_alpha=T(g["eps_alpha"]), eps_rgb=T(g["eps_rgb"]))
+    close(raw_x, g["raw_x"], what="raw of the [P, 54] input")
+    close(ent_x.reshape(-1)[0], g["loss_entropy_x"], what="entropy of the [P, 54] input")
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    tr = TR.Trainer(net, beta1=float(g["beta1"]))
+    eps = torch.cat([T(g["eps_rgb"]), T(g["eps_alpha"])], -1).to(DEV)
+    grad = tr.forward_backward(H, W, focal, T(g["rays"]).to(DEV), T(g["target"]).to(DEV), t_rand=T(g["t_rand"]).to(DEV), eps=eps).cpu()
+    close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    close(tr.depth, g["depth_map"], what="depth_map")
+    close(tr.disp, g["disp_map"], atol=1e-4, rtol=1e-3, what="disp_map")
+    close(tr.scalars[0].cpu(), g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    close(tr.scalars[1].cpu(), g["loss_nll"], atol=1e-5, rtol=1e-4, what="loss_nll")
+    close(tr.entropy.cpu().reshape(()), g["loss_entropy"], atol=1e-5, rtol=1e-4, what="entropy")
+    packed = O.pack_rays(H, W, focal, T(g["rays"])[0], T(g["rays"])[1], True, 0., 1.)
+    corr, _ = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    n = 0
+    for key, (off, cnt) in net.layout.items():
+        if ("grad." + key) in g:
+            grad_close(grad[off:off + cnt].reshape(g["grad." + key].shape), g["grad." + key] + corr[key], "grad " + key)
+            n += 1
+        else:
+            assert not grad[off:off + cnt].any(), key
+    assert n >= 30
+    net.sample_alpha, net.sample_rgb = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        rgbs_e, _, depth_e, _ = cfnerf_amd.render(H, W, focal, rays=T(g["rays"]).to(DEV), near=0., far=1., **kw_test)
+    close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth_e, g["depth_map_eval"], what="depth_map_eval")
+
+
+def test_train_step_authors_recipe_w512_vs_reference_golden(golden):
+    """G21: the AUTHORS' recipe (train_NF.sh:1-19: netwidth 512, h_alpha 64, h_rgb 64, K 32; configs/africa_ds.txt: no NDC) through the
+    REAL reference.  fused_fwd_kernel<512> (8 waves) and bwd_data_kernel<512> (arguments by value, one workgroup per CU) run a different
+    register / argument scheme from W <= 256 and were pinned through the oracle only.  Outputs, loss, entropy; of every gradient tensor
+    64 sampled entries (mask-corrected like the other fixtures), its Frobenius norm and its sum; one fused Adam step on the same entries;
+    eval render."""
+    g = golden("g21_train_authors_recipe_w512")
+    cfg = cfg_from(g)
+    assert (cfg.netwidth, cfg.h_alpha_size, cfg.h_rgb_size, cfg.K_samples) == (512, 64, 64, 32)
+    _, kw_train, kw_test, model, p, _ = build_model(cfg, int(g["seed"]), no_ndc=True)
+    net = model.module
+    H, W, focal, near, far = int(g["H"]), int(g["W"]), float(g["focal"]), float(g["near"]), float(g["far"])
+    tr = TR.Trainer(net, lrate=5e-4, beta1=float(g["beta1"]))
+    eps = torch.cat([T(g["eps_rgb"]), T(g["eps_alpha"])], -1).to(DEV)
+    kw = dict(t_rand=T(g["t_rand"]).to(DEV), eps=eps, near=near, far=far, ndc=False)
+    grad = tr.forward_backward(H, W, focal, T(g["rays"]).to(DEV), T(g["target"]).to(DEV), **kw).cpu().clone()
+    close(tr.rgb_map, g["rgb_map"], what="rgb_map")
+    close(tr.depth, g["depth_map"], what="depth_map")
+    close(tr.disp, g["disp_map"], atol=1e-4, rtol=1e-3, what="disp_map")
+    close(tr.scalars[0].cpu(), g["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    close(tr.scalars[1].cpu(), g["loss_nll"], atol=1e-5, rtol=1e-4, what="loss_nll")
+    close(tr.entropy.cpu().reshape(()), g["loss_entropy"], atol=1e-5, rtol=1e-4, what="entropy")
+    packed = O.pack_rays(H, W, focal, T(g["rays"])[0], T(g["rays"])[1], False, near, far)
+    corr, n_flips = mask_corrected(net, p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    n = 0
+    for key, (off, cnt) in net.layout.items():
+        gk = grad[off:off + cnt].double().numpy()
+        if ("gradsample." + key) not in g:
+            assert not gk.any(), f"{key} must get a zero gradient"
+            continue
+        idx = g["gradidx." + key]
+        scale = max(float(g["gradabsmax." + key]), 1e-12)
+        ref = g["gradsample." + key].astype(np.float64) + corr[key].reshape(-1)[idx]
+        assert np.abs(gk[idx] - ref).max() <= G_TIGHT * scale + 1e-4 * np.abs(ref).max(), \
+            f"gradsample {key}: {np.abs(gk[idx] - ref).max() / scale:.2e} of the largest entry"
+        corr_norm = float(np.linalg.norm(corr[key].astype(np.float64)))
+        assert abs(float(np.linalg.norm(gk)) - float(g["gradnorm." + key])) <= 2e-3 * float(g["gradnorm." + key]) + corr_norm, "gradnorm " + key
+        assert abs(float(gk.sum()) - float(g["gradsum." + key]) - float(corr[key].astype(np.float64).sum())) <= G_TIGHT * scale * np.sqrt(cnt) + 1e-3 * abs(float(g["gradsum." + key])), \
+            "gradsum " + key
+        n += 1
+    assert n >= 30
+    tr.step(H, W, focal, T(g["rays"]).to(DEV), T(g["target"]).to(DEV), **kw)      # one fused Adam step (RUN:339,1067)
+    for key in net.layout:
+        if ("adam1sample." + key) in g:
+            d = (net.view(key).cpu().reshape(-1)[T(g["gradidx." + key]).long()] - T(g["adam1sample." + key])).abs()
+            assert float(d.max()) <= 2 * 5e-4 + 1e-6, "adam " + key             # lr * sign(g): a ~0 gradient may flip sign
+            assert float((d > 2e-5).float().mean()) <= 0.05, f"adam {key}: {float((d > 2e-5).float().mean()):.3%} of the sampled entries moved"
+    # eval render at the fixture's weights (Adam moved them)
+    sd = model.state_dict()
+    for k, v in p.items():
+        sd["module." + k] = v
+    model.load_state_dict(sd)
+    net.sample_alpha, net.sample_rgb = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    with torch.no_grad():
+        rgbs_e, _, depth_e, _ = cfnerf_amd.render(H, W, focal, rays=T(g["rays"]).to(DEV), near=near, far=far, **kw_test)
+    close(rgbs_e, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth_e, g["depth_map_eval"], what="depth_map_eval")
+
+
+@pytest.mark.parametrize("mr,mrv,W,K,N", [(6, 2, 256, 4, 20), (1, 1, 64, 3, 12), (10, 1, 128, 2, 9), (4, 4, 256, 16, 6), (3, 3, 512, 5, 5), (9, 2, 192, 4, 7)])
+def test_non_default_multires_forward_and_gradients_vs_oracle(mr, mrv, W, K, N):
+    """--multires / --multires_views other than 10 / 4 (RUN:641-644; cfnerf_model_create accepts 1..10 / 1..4): the network on an
+    encoded input, a train-mode render, loss and every gradient against the oracle (pinned at (6, 2) by fixture G20)."""
+    cfg = O.OracleCfg(netwidth=W, K_samples=K, multires=mr, multires_views=mrv, h_alpha_size=64 if W == 512 else 32)
+    args, kw_train, _, model, p, _ = build_model(cfg, 900 + 10 * mr + mrv)
+    assert (args.input_ch, args.input_ch_views) == (3 + 6 * mr, 3 + 6 * mrv)
+    net = model.module
+    gen = torch.Generator().manual_seed(mr * 16 + mrv)
+    x = torch.rand(70, cfg.input_ch + cfg.input_ch_views, generator=gen) * 2 - 1
+    ea, er = torch.randn(K, 1, generator=gen), torch.randn(K, 3, generator=gen)
+    with torch.no_grad():
+        raw_t, ent = net(x.to(DEV), False, False, eps_alpha=ea, eps_rgb=er)
+    raw_o, ent_o = O.nerf_flows_forward(p, x, ea, er, cfg, is_test=False)
+    close(raw_t, raw_o, what="raw")
+    close(ent.reshape(-1)[0], ent_o, what="entropy")
+    rng = np.random.default_rng(mr * 100 + mrv)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    beta1 = 0.05
+    tr = TR.Trainer(net, beta1=beta1)
+    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.cat([er, ea], -1).to(DEV)).cpu()
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret, n_flips = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1)
+    close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map")
+    close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map")
+    close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss")
+    check_all_grads(net, grad, grads, f"[multires={mr}/{mrv} W={W} K={K} N={N}, {n_flips} masks differ]")
 
 
 def test_three_steps_vs_reference_golden(golden):
@@ -652,48 +786,135 @@ def _fuzz_seeds():
 def test_random_configurations_forward_and_gradients_vs_oracle(seed):
     """Seeded random draw over the supported configuration space (width, depth, K, head sizes, batch, NDC / lindisp /
     white background, jitter on or off): render outputs, loss and every gradient against the CPU oracle."""
-    rng = np.random.default_rng(9000 + seed)
-    W = int(rng.choice([64, 128, 192, 256, 320] if seed < 1000 else [64, 128, 192, 256, 320, 384, 448, 512]))   # (soak seeds >= 1000: every width)
-    D = int(rng.choice([4, 5, 6, 8]))
-    K = int(rng.choice([2, 3, 4, 5, 6, 16, 32, 72]))
-    ha = int(rng.choice([32, 64, 96, 128] if W <= 256 else [32, 64, 96]))
-    hr = int(rng.choice([h for h in (32, 64, 96, 128) if W // 2 + h <= max(W, 128)]))
-    N = int(rng.integers(3, 24))
-    if seed >= 3000:                                     # (soak: MANY rays through a small network - every workgroup walks several rays)
-        W, D, K, ha, hr, N = 64, int(rng.choice([4, 5])), int(rng.choice([2, 3, 4])), 32, 32, int(rng.integers(600, 1500))
-    ndc = bool(rng.integers(0, 2))
-    lindisp = (not ndc) and bool(rng.integers(0, 2))
-    wb = bool(rng.integers(0, 2))
-    perturb = bool(rng.integers(0, 4))                   # mostly on
-    nf = int(rng.choice([4, 4, 4, 3, 2]))
-    cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr, n_flows=nf)
-    _, kw_train, _, model, p, _ = build_model(cfg, 700 + seed, no_ndc=not ndc, lindisp=lindisp, white_bkgd=wb)
-    net = model.module
-    import os
-    if os.environ.get("CFNERF_FUZZ_PREC"):               # soak of the opt-in mode: CFNERF_FUZZ_PREC=bf16x3
-        net.set_precision(os.environ["CFNERF_FUZZ_PREC"])
-    rays, (H, Wd, focal) = fern_rays(rng, N)
-    near, far = (0., 1.) if ndc else (1.2, 8.0)
-    # (soak seeds >= 2000: sample tables other than the reference's 128 entries - ragged last tile, one tile, many tiles)
-    S = 128 if seed < 2000 else int(rng.choice([16, 64, 100, 128, 130, 192, 257]))
-    t_vals = None if S == 128 else torch.linspace(0., 1., S)
-    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32) if perturb else None
-    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
-    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
-    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
-    beta1 = float(rng.choice([0.0, 0.01, 0.1]))
-    tr = TR.Trainer(net, beta1=beta1)
-    grad = tr.forward_backward(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=None if t_rand is None else t_rand.to(DEV),
-                               eps=torch.cat([er, ea], -1).to(DEV), near=near, far=far, ndc=ndc, lindisp=lindisp, white_bkgd=wb,
-                               perturb=1. if perturb else 0., t_vals=None if t_vals is None else t_vals.to(DEV)).cpu()
-    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
-    scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=lindisp, white_bkgd=wb,
-                                                         t_vals=t_vals)
+    c = fuzz_case(seed)
+    W, D, K, ha, hr, nf, N, S = c["W"], c["D"], c["K"], c["ha"], c["hr"], c["nf"], c["N"], c["S"]
+    ndc, lindisp, wb, perturb, beta1 = c["ndc"], c["lindisp"], c["wb"], c["perturb"], c["beta1"]
+    cfg, p, net, tr, grad = c["cfg"], c["p"], c["net"], c["tr"], c["grad"]
+    scal, grads, ret, _ = oracle_train_step_on_hip_masks(net, p, c["packed"], c["target"], cfg, c["ea"], c["er"], c["t_rand"], beta1, lindisp=lindisp,
+                                                         white_bkgd=wb, t_vals=c["t_vals"])
     what = f"[W={W} D={D} K={K} ha={ha} hr={hr} F={nf} N={N} S={S} ndc={ndc} lindisp={lindisp} wb={wb} perturb={perturb} beta1={beta1}]"
     close(tr.rgb_map.cpu(), ret["rgb_map"], atol=1e-5, rtol=1e-4, what="rgb_map " + what)
     close(tr.depth.cpu(), ret["depth_map"], atol=1e-5, rtol=1e-4, what="depth_map " + what)
     close(tr.scalars[0].cpu(), scal["loss"], atol=1e-5, rtol=1e-4, what="loss " + what)
     check_all_grads(net, grad, grads, what)
+
+
+K2_DRAWS = {   # soak draws whose FULL-step gradient comparison exceeded its bound in round 4 (seeds 5027 / 5029: K = 2, W = 64, many rays), and two
+               # fresh K = 2 draws through the default width (same seed family, W / depth / sample count forced after the draw)
+    "seed5027_w64_771x257": (5027, {}),
+    "seed5029_w64_1459x16": (5029, {}),
+    "seed5101_w256_767x64": (5101, dict(W=256, D=8, K=2, hr=64, S=64)),
+    "seed5102_w256_1020x64": (5102, dict(W=256, D=8, K=2, hr=64, S=64)),
+}
+
+
+@pytest.mark.parametrize("name", list(K2_DRAWS))
+def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
+    """Settles the round-4 soak failures (tests/tools/k2_grad_diag.py).  At K = 2 the KDE bandwidth H = std_K * 2 * 0.4^(-1/7)
+    (RUN:1032-1042) is a few 1e-3 wherever a ray's two latent colours nearly coincide, and the loss gradient d loss / d rgb_map moves by
+    8e-5 .. 1e-4 (RMS, relative) when rgb_map moves by the 2e-7 .. 2e-6 that two correct fp32 forwards differ by - 45 x .. 450 x.  A
+    comparison of the full step against the fp64 oracle therefore measures the loss's steepness, not the backward kernels (measured on
+    these draws: full-step error 5e-5 .. 3e-4 on the rgb-path flow heads; with the SAME cotangent on both sides 4e-7 .. 6e-7).
+    So the step is judged in its three links, each against fp64 at ITS OWN input:
+      (a) the forward (rgb_map, depth, loss, entropy) at the path's forward tolerance;
+      (b) the loss kernel's d loss / d rgb_map against the fp64 loss gradient evaluated at the HIP rgb_map: 5e-6 of its largest entry;
+      (c) the fused backward fed that fp64 gradient (cast to fp32) against the fp64 oracle differentiated with the same cotangent on the
+          HIP masks: EVERY tensor within max(G_FLOOR, 8 x what the fp32 CPU oracle loses on the same differentiation) of its largest
+          entry and of its RMS, capped at G_CAP_OTHER (G_CAP on the density path) - no sum|c| allowance, no conditioning term;
+      (d) coverage, one ray at a time (first / last ray, both sides of the 4-ray workgroup and 64-ray boundaries, the middle, random
+          ones): a one-hot cotangent against the fp64 oracle on that ray alone.  Outside the density path: max(G_FLOOR, 8 x fp32 noise),
+          cap G_CAP_OTHER.  On the density path a single ray's gradient is the difference of nearly equal transmittance terms (measured
+          at K = 2: HIP up to 4.5e-3, the fp32 CPU oracle up to 7e-3 of the largest entry, either may be the worse one): 2e-2 - a dropped or
+          doubled k-part or tile of the ray is an error of >= 0.25."""
+    from util_hip import G_CAP, G_CAP_OTHER, G_FLOOR, fuzz_case, hip_relu_masks
+    import ctypes as C
+    from cfnerf_amd import _lib as L
+    seed, force = K2_DRAWS[name]
+    c = fuzz_case(seed, **force)
+    net, p, cfg, tr = c["net"], c["p"], c["cfg"], c["tr"]
+    N, S, K, beta1 = c["N"], c["S"], c["K"], c["beta1"]
+    assert K == 2 and N >= 700
+    d = lambda t: None if t is None else t.double()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300))
+    rms = lambda a, b: float(((a.double() - b.double()) ** 2).sum().sqrt() / (b.double() ** 2).sum().sqrt().clamp_min(1e-300))
+    lib = L.lib()
+
+    def hip_bwd(d_rgb, with_entropy):
+        gout = torch.empty(net.n_params, device=DEV)
+        L.check(lib.cfnerf_render_bwd(net.handle, lib.cfnerf_model_stash_generation(net.handle), L.ptr(d_rgb.float().to(DEV).contiguous()), None,
+                                      L.ptr(tr.d_ent) if with_entropy else None, L.ptr(gout), L.stream()), "cfnerf_render_bwd")
+        return gout.cpu().double()
+    masks = hip_relu_masks(net, N * S)[1]
+    keys = list(net.layout)
+    with O.relu_override(masks=masks):
+        q = {k: d(v).clone().requires_grad_(True) for k, v in p.items()}
+        r64 = O.render_rays(q, d(c["packed"]), cfg, d(c["ea"]), d(c["er"]), True, d(c["t_rand"]), c["lindisp"], c["wb"], t_vals=d(c["t_vals"]))
+        q32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        r32 = O.render_rays(q32, c["packed"], cfg, c["ea"], c["er"], True, c["t_rand"], c["lindisp"], c["wb"], t_vals=c["t_vals"])
+    # (a) forward
+    close(tr.rgb_map.cpu(), r64["rgb_map"].detach(), atol=1e-5, rtol=1e-4, what="rgb_map")
+    close(tr.depth.cpu(), r64["depth_map"].detach(), atol=1e-5, rtol=1e-4, what="depth_map")
+    close(tr.entropy.cpu().reshape(()), r64["loss_entropy"].detach(), atol=1e-5, rtol=1e-4, what="entropy")
+    # (b) loss kernel at its own input
+    rgb_h = tr.rgb_map.detach().cpu().double().requires_grad_(True)
+    Lh = O.train_loss(rgb_h, d(c["target"]), r64["loss_entropy"].detach(), K, beta1)
+    (Gh,) = torch.autograd.grad(Lh["loss"], rgb_h)
+    close(tr.scalars[1].cpu(), Lh["loss_nll"].detach(), atol=1e-5, rtol=1e-4, what="loss_nll at the HIP rgb_map")
+    assert rel(tr.d_rgb.cpu(), Gh) <= 5e-6, f"loss kernel's d_rgb: {rel(tr.d_rgb.cpu(), Gh):.2e} of the largest entry"
+    rgb_o = r64["rgb_map"].detach().clone().requires_grad_(True)
+    (Go,) = torch.autograd.grad(O.train_loss(rgb_o, d(c["target"]), r64["loss_entropy"].detach(), K, beta1)["loss"], rgb_o)
+    amp = rms(Gh, Go) / max(rms(tr.rgb_map.cpu(), r64["rgb_map"].detach()), 1e-300)
+    # (c) the backward, same cotangent on both sides
+    Ghf = Gh.float()
+    g_iso = hip_bwd(Ghf, bool(beta1))
+    outs, cots, outs32, cots32 = [r64["rgb_map"]], [Ghf.double()], [r32["rgb_map"]], [Ghf]
+    if beta1:
+        outs.append(r64["loss_entropy"]); cots.append(torch.tensor(float(beta1), dtype=torch.float64))
+        outs32.append(r32["loss_entropy"]); cots32.append(torch.tensor(float(beta1)))
+    ref = dict(zip(keys, torch.autograd.grad(outs, [q[k] for k in keys], cots, retain_graph=True, allow_unused=True)))
+    ref32 = dict(zip(keys, torch.autograd.grad(outs32, [q32[k] for k in keys], cots32, allow_unused=True)))
+    worst = ("", 0.0, 0.0)
+    for k in keys:
+        off, cnt = net.layout[k]
+        if ref[k] is None or float(ref[k].abs().max()) == 0.0:
+            assert not g_iso[off:off + cnt].any(), k
+            continue
+        g = g_iso[off:off + cnt].reshape(ref[k].shape)
+        cap = G_CAP if "alpha" in k else G_CAP_OTHER
+        e_max, e_rms, n_max, n_rms = rel(g, ref[k]), rms(g, ref[k]), rel(ref32[k], ref[k]), rms(ref32[k], ref[k])
+        assert e_max <= min(max(G_FLOOR, 8 * n_max), cap), f"isolated backward, {k}: {e_max:.2e} of the largest entry (fp32 CPU oracle {n_max:.1e})"
+        assert e_rms <= min(max(1.5 * G_FLOOR, 8 * n_rms), cap), f"isolated backward, {k}: RMS error {e_rms:.2e} of the RMS (fp32 CPU oracle {n_rms:.1e})"
+        if e_max > worst[1]:
+            worst = (k, e_max, n_max)
+    print(f"{name}: rgb_map HIP vs fp64 {rel(tr.rgb_map.cpu(), r64['rgb_map'].detach()):.1e}; the loss gradient moves by {rms(Gh, Go):.1e} (RMS) between the two forward points "
+          f"= {amp:.0f} x the rgb_map difference; isolated backward: worst tensor {worst[0]} {worst[1]:.1e} (fp32 CPU oracle {worst[2]:.1e})")
+    # (d) one ray at a time
+    rng = np.random.default_rng(seed)
+    rays_i = list(dict.fromkeys([0, 3, 4, 63, 64, N // 2, N - 1] + [int(x) for x in rng.integers(0, N, 3)]))
+    assert len(rays_i) >= 8
+    for i in rays_i:
+        Gi = torch.tensor(rng.standard_normal((3, K)), dtype=torch.float32)
+        G = torch.zeros(N, 3, K)
+        G[i] = Gi
+        g_hip = hip_bwd(G, False)
+        m_i = {k: v[i * S:(i + 1) * S] for k, v in masks.items()}
+        tr_i = None if c["t_rand"] is None else c["t_rand"][i:i + 1]
+        qi = {k: d(v).clone().requires_grad_(True) for k, v in p.items()}
+        qj = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        with O.relu_override(masks=m_i):
+            ri = O.render_rays(qi, d(c["packed"][i:i + 1]), cfg, d(c["ea"]), d(c["er"]), True, d(tr_i), c["lindisp"], c["wb"], t_vals=d(c["t_vals"]))
+            rj = O.render_rays(qj, c["packed"][i:i + 1], cfg, c["ea"], c["er"], True, tr_i, c["lindisp"], c["wb"], t_vals=c["t_vals"])
+        (ri["rgb_map"] * d(Gi)[None]).sum().backward()
+        (rj["rgb_map"] * Gi[None]).sum().backward()
+        for k in keys:
+            off, cnt = net.layout[k]
+            gk = qi[k].grad
+            if gk is None or float(gk.abs().max()) == 0.0:
+                assert not g_hip[off:off + cnt].any(), (i, k)
+                continue
+            e = rel(g_hip[off:off + cnt].reshape(gk.shape), gk)
+            tol = 2e-2 if "alpha" in k else min(max(G_FLOOR, 8 * rel(qj[k].grad, gk)), G_CAP_OTHER)
+            assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e}"
 
 
 def test_one_hot_cotangent_reaches_every_ray_at_production_batch():

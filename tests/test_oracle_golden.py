@@ -21,7 +21,8 @@ def close(a, b, atol=2e-6, rtol=2e-5, what=""):
 
 def cfg_from(g):
     return O.OracleCfg(netwidth=int(g["netwidth"]), K_samples=int(g["K"]), netdepth=int(g.get("netdepth", 8)), n_flows=int(g.get("n_flows", 4)),
-                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)))
+                       h_alpha_size=int(g.get("h_alpha_size", 32)), h_rgb_size=int(g.get("h_rgb_size", 64)),
+                       multires=int(g.get("multires", 10)), multires_views=int(g.get("multires_views", 4)))
 
 
 def test_encoder(golden):
@@ -352,6 +353,82 @@ def test_train_step_wide_config(golden):
             close(grads[k].double().norm(), g["gradnorm." + k], atol=0, rtol=1e-4, what="gradnorm " + k)
             n += 1
     assert n >= 26
+    ea, er = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    ea[-1] = 0
+    er[-1] = 0
+    e = O.render_rays(p, packed, cfg, ea, er, False)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")
+
+
+def test_train_step_non_default_multires(golden):
+    """G20: --multires 6 --multires_views 2 (RUN:641-644, HLP:54-69): 39 + 15 input channels through the real reference - model forward on
+    a [P, 54] input, render, loss, every gradient, eval render"""
+    g = golden("g20_train_multires_6_2")
+    cfg = cfg_from(g)
+    assert (cfg.multires, cfg.multires_views, cfg.input_ch, cfg.input_ch_views) == (6, 2, int(g["input_ch"]), int(g["input_ch_views"])) == (6, 2, 39, 15)
+    shapes = O.param_shapes(cfg)
+    for k in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight"):
+        assert list(shapes[k]) == list(g["shape." + k]), k
+    p = O.make_params(cfg, int(g["seed"]))
+    raw_x, ent_x = O.nerf_flows_forward(p, T(g["x54"]), T(g["eps_alpha"]), T(g["eps_rgb"]), cfg, is_test=False)
+    close(raw_x, g["raw_x"], atol=5e-6, rtol=5e-5, what="raw of the [P, 54] input")
+    close(ent_x, g["loss_entropy_x"], atol=2e-6, rtol=2e-5, what="entropy of the [P, 54] input")
+    rays = T(g["rays"])
+    packed = O.pack_rays(int(g["H"]), int(g["W"]), float(g["focal"]), rays[0], rays[1], True, 0., 1.)
+    scal, grads, ret = O.train_step(p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    close(ret["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(ret["raw"][:2], g["raw_first2"], atol=5e-6, rtol=5e-5, what="raw")
+    close(scal["loss"], g["loss"], rtol=2e-5, what="loss")
+    close(scal["loss_entropy"], g["loss_entropy"], atol=2e-6, rtol=2e-5, what="entropy")
+    n = 0
+    for k in p:
+        if ("grad." + k) in g:
+            ref = g["grad." + k]
+            close(grads[k], ref, atol=2e-4 * max(1e-7, float(np.abs(ref).max())), rtol=1e-3, what="grad " + k)
+            n += 1
+    assert n >= 30
+    ea, er = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
+    ea[-1] = 0
+    er[-1] = 0
+    e = O.render_rays(p, packed, cfg, ea, er, False)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")
+
+
+def test_train_step_authors_recipe_w512(golden):
+    """G21: the authors' recipe (train_NF.sh:1-19: netwidth 512, h_alpha 64, h_rgb 64, K 32; africa_ds.txt: no NDC) through the real
+    reference: outputs, loss, and of every gradient 64 sampled entries + Frobenius norm + sum; one Adam step on the same entries"""
+    g = golden("g21_train_authors_recipe_w512")
+    cfg = cfg_from(g)
+    assert (cfg.netwidth, cfg.h_alpha_size, cfg.h_rgb_size, cfg.K_samples) == (512, 64, 64, 32)
+    p = O.make_params(cfg, int(g["seed"]))
+    rays = T(g["rays"])
+    packed = O.pack_rays(int(g["H"]), int(g["W"]), float(g["focal"]), rays[0], rays[1], False, float(g["near"]), float(g["far"]))
+    scal, grads, ret = O.train_step(p, packed, T(g["target"]), cfg, T(g["eps_alpha"]), T(g["eps_rgb"]), T(g["t_rand"]), float(g["beta1"]))
+    close(ret["rgb_map"], g["rgb_map"], atol=5e-6, rtol=5e-5, what="rgb_map")
+    close(ret["depth_map"], g["depth_map"], atol=5e-6, rtol=5e-5, what="depth_map")
+    close(ret["raw"][:1], g["raw_first1"], atol=5e-6, rtol=5e-5, what="raw")
+    close(scal["loss"], g["loss"], rtol=2e-5, what="loss")
+    close(scal["loss_entropy"], g["loss_entropy"], atol=2e-6, rtol=2e-5, what="entropy")
+    n = 0
+    state = {}
+    for k in p:
+        if ("gradsample." + k) not in g:
+            assert grads[k] is None or not grads[k].any(), k
+            continue
+        idx = T(g["gradidx." + k]).long()
+        scale = max(1e-7, float(g["gradabsmax." + k]))
+        close(grads[k].reshape(-1)[idx], g["gradsample." + k], atol=2e-4 * scale, rtol=1e-3, what="gradsample " + k)
+        close(grads[k].double().norm(), g["gradnorm." + k], atol=0, rtol=2e-4, what="gradnorm " + k)
+        close(grads[k].double().sum(), g["gradsum." + k], atol=2e-4 * scale * np.sqrt(grads[k].numel()), rtol=1e-3, what="gradsum " + k)
+        n += 1
+    assert n >= 30
+    live = {k: v for k, v in grads.items() if v is not None}
+    new = O.adam_step({k: p[k] for k in live}, live, state, 1, 5e-4)
+    for k in live:
+        idx = T(g["gradidx." + k]).long()
+        d = (new[k].reshape(-1)[idx] - T(g["adam1sample." + k])).abs()
+        assert float(d.max()) <= 2 * 5e-4 + 1e-6, k                    # Adam's first step is lr * sign(g): a ~0 gradient may flip
+        assert float((d > 2e-5).float().mean()) <= 0.05, k
     ea, er = T(g["eps_alpha"]).clone(), T(g["eps_rgb"]).clone()
     ea[-1] = 0
     er[-1] = 0

@@ -10,7 +10,8 @@ from oracle import cfnerf_oracle as O
 from util_hip import build_model, fern_rays
 
 def stash(net, name, layer, n):
-    lib = C.CDLL(L.LIB_PATH)
+    import hooks
+    lib = hooks.lib()
     lib.cfnerf_debug_copy_stash.restype = C.c_int64
     lib.cfnerf_debug_copy_stash.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     out = torch.empty(n, device="cuda")

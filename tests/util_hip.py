@@ -79,9 +79,9 @@ G_TIGHT = 2e-4            # of the tensor's largest entry
 def stash_copy(net, name, layer, n, keep=None):
     """buffer `name` of the last STASH forward as a CPU tensor; keep = (lo, hi): only that range of its floats crosses to the host"""
     import ctypes as C
+    import hooks
     from cfnerf_amd import _lib as L
-    lib = L.lib()
-    fn = lib.cfnerf_debug_copy_stash
+    fn = hooks.lib().cfnerf_debug_copy_stash            # (test library: the product .so exports include/cfnerf.h only)
     fn.restype = C.c_int64
     fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     out = torch.empty(n, device="cuda")
@@ -246,3 +246,56 @@ def grad_close_tight(g, ref, what, tol=None):
     close(g, ref, atol=tol * scale + floor, rtol=1e-4, what=what)
     rms_ref = float(np.sqrt((ref ** 2).mean()))
     assert rms_rel * rms_ref <= tol_rms * rms_ref + floor, f"{what}: RMS error {rms_rel:.2e} of the tensor's RMS exceeds {tol_rms:.1e}"
+
+
+def fuzz_case(seed, run=True, **force):
+    """The seeded random draw of tests/test_hip_train.py::test_random_configurations_forward_and_gradients_vs_oracle, as a function so that
+    the named regression cases and tests/tools/k2_grad_diag.py replay EXACTLY the draw a soak seed made.  Seeds >= 1000: every width;
+    >= 2000: sample tables other than the reference's 128 entries; >= 3000: MANY rays through a small network (every workgroup walks
+    several rays).  `force` overrides drawn values AFTER the draw (the stream of random numbers stays the seed's): W, D, K, ha, hr, N, S.
+    Returns the configuration, the inputs and - with `run` - the model, the Trainer and its flat gradient of the step."""
+    from cfnerf_amd import train as TR
+    rng = np.random.default_rng(9000 + seed)
+    W = int(rng.choice([64, 128, 192, 256, 320] if seed < 1000 else [64, 128, 192, 256, 320, 384, 448, 512]))
+    D = int(rng.choice([4, 5, 6, 8]))
+    K = int(rng.choice([2, 3, 4, 5, 6, 16, 32, 72]))
+    ha = int(rng.choice([32, 64, 96, 128] if W <= 256 else [32, 64, 96]))
+    hr = int(rng.choice([h for h in (32, 64, 96, 128) if W // 2 + h <= max(W, 128)]))
+    N = int(rng.integers(3, 24))
+    if seed >= 3000:
+        W, D, K, ha, hr, N = 64, int(rng.choice([4, 5])), int(rng.choice([2, 3, 4])), 32, 32, int(rng.integers(600, 1500))
+    ndc = bool(rng.integers(0, 2))
+    lindisp = (not ndc) and bool(rng.integers(0, 2))
+    wb = bool(rng.integers(0, 2))
+    perturb = bool(rng.integers(0, 4))                   # mostly on
+    nf = int(rng.choice([4, 4, 4, 3, 2]))
+    W, D, K, ha, hr, N = (force.get("W", W), force.get("D", D), force.get("K", K), force.get("ha", ha), force.get("hr", hr), force.get("N", N))
+    cfg = O.OracleCfg(netwidth=W, netdepth=D, K_samples=K, h_alpha_size=ha, h_rgb_size=hr, n_flows=nf)
+    c = dict(seed=seed, W=W, D=D, K=K, ha=ha, hr=hr, nf=nf, N=N, ndc=ndc, lindisp=lindisp, wb=wb, perturb=perturb, cfg=cfg)
+    if run:
+        _, kw_train, _, model, p, _ = build_model(cfg, 700 + seed, no_ndc=not ndc, lindisp=lindisp, white_bkgd=wb)
+        net = model.module
+        if os.environ.get("CFNERF_FUZZ_PREC"):           # soak of the opt-in mode: CFNERF_FUZZ_PREC=bf16x3
+            net.set_precision(os.environ["CFNERF_FUZZ_PREC"])
+        c.update(kw_train=kw_train, model=model, net=net, p=p)
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    near, far = (0., 1.) if ndc else (1.2, 8.0)
+    S = 128 if seed < 2000 else int(rng.choice([16, 64, 100, 128, 130, 192, 257]))
+    S = force.get("S", S)
+    t_vals = None if S == 128 else torch.linspace(0., 1., S)
+    t_rand = torch.tensor(rng.uniform(0, 1, (N, S)), dtype=torch.float32) if perturb else None
+    ea = torch.tensor(rng.standard_normal((K, 1)), dtype=torch.float32)
+    er = torch.tensor(rng.standard_normal((K, 3)), dtype=torch.float32)
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32)
+    beta1 = float(rng.choice([0.0, 0.01, 0.1]))
+    packed = O.pack_rays(H, Wd, focal, rays[0], rays[1], ndc, near, far)
+    c.update(S=S, rays=rays, H=H, Wd=Wd, focal=focal, near=near, far=far, t_vals=t_vals, t_rand=t_rand, ea=ea, er=er, target=target,
+             beta1=beta1, packed=packed)
+    if run:
+        tr = TR.Trainer(net, beta1=beta1)
+        dev = "cuda"
+        c["fb_kw"] = dict(t_rand=None if t_rand is None else t_rand.to(dev), eps=torch.cat([er, ea], -1).to(dev), near=near, far=far, ndc=ndc,
+                          lindisp=lindisp, white_bkgd=wb, perturb=1. if perturb else 0., t_vals=None if t_vals is None else t_vals.to(dev))
+        grad = tr.forward_backward(H, Wd, focal, rays.to(dev), target.to(dev), **c["fb_kw"]).cpu()
+        c.update(tr=tr, grad=grad)
+    return c

@@ -1,6 +1,7 @@
 #!/bin/bash
-# build a VARIANT of the library for same-box A/B runs (tools/ab_bench.sh, CFNERF_LIB=...):
-#   tools/build_variant.sh <name> [-DFLAG ...]   ->  cf-nerf_amd/libvar_<name>.so   (git-ignored, travels with gpurun)
+# build a VARIANT of the library for same-box A/B runs (tools/ab_kernels.sh, CFNERF_LIB=...) from the CURRENT tree - e.g. with an
+# experiment applied as a patch, or extra compiler flags (the concluded CFN_* source switches of rounds 2-4 are gone: profiles/EXPERIMENTS.md):
+#   tools/build_variant.sh <name> [compiler flags ...]   ->  cf-nerf_amd/libvar_<name>.so   (git-ignored, travels with gpurun)
 set -euo pipefail
 R="$(cd "$(dirname "$0")/.." && pwd)"
 name="$1"; shift
