@@ -283,6 +283,7 @@ class NeRF_Flows(nn.Module):
         if draw_latents:
             self.sample_alpha, self.sample_rgb = latents    # eval latents: plain attributes, NOT in state_dict
         self._dirty = True
+        self.params_serial += 1             # (writes through .data views do not move flat._version)
 
     def reset_parameters(self):
         """Fresh nn.Linear default init (U(+-1/sqrt(fan_in)) for weight and bias), base Gaussians mean 0 / std 1; the
@@ -322,6 +323,7 @@ class NeRF_Flows(nn.Module):
                 elif strict:
                     missing_keys.append(k)
         self._dirty = True                  # re-pack before the next launch
+        self.params_serial += 1             # (writes through .data views do not move flat._version): a pending backward must notice
         if strict:
             for k in state_dict:
                 if k.startswith(prefix) and k[len(prefix):] not in self.layout and k[len(prefix):] not in bufs:
@@ -450,6 +452,22 @@ class NeRF_Flows(nn.Module):
                 pass
 
 
+def _params_token(model):
+    """Identifies "the weights of a forward": torch in-place ops on ``flat`` (optimizer.step) move ``flat._version``; everything that
+    writes through the raw pointer or a ``.data`` view (the fused Adam kernel, load_state_dict, mark_dirty) bumps ``params_serial``."""
+    return (model.flat._version, model.params_serial)
+
+
+def _refuse_changed_params(model, token):
+    """A backward differentiates the activations of ITS forward against the packed weights the library holds NOW: if the parameters were
+    replaced in between (optimizer.step / Trainer.step through the same handle / load_state_dict before backward()), the result would
+    be silently wrong whether or not the activation stash is still the forward's - torch autograd raises in this situation, so do we."""
+    if _params_token(model) != token:
+        raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: the "
+                           "parameters of NeRF_Flows changed between this forward and its backward (call backward() before "
+                           "optimizer.step() / Trainer.step() / load_state_dict())")
+
+
 class _NetworkFn(torch.autograd.Function):
     """NeRF_Flows.forward as an autograd node: cfnerf_network_fwd with the activation stash + cfnerf_network_bwd.  The model has
     ONE stash.  If a later grad-enabled forward replaced it before this node's backward runs (several chunks of one batch through
@@ -472,21 +490,16 @@ class _NetworkFn(torch.autograd.Function):
         ent = torch.zeros(1, device=xf.device)
         ctx.generation = _NetworkFn._forward_stash(model, xf, eps, raw, ent)
         ctx.model, ctx.xf, ctx.eps, ctx.n_params = model, xf, eps, flat.numel()
-        ctx.params_at = (flat._version, model.params_serial)       # the weights this graph was taken at
+        ctx.params_at = _params_token(model)                       # the weights this graph was taken at
         return raw, ent.reshape(())
 
     @staticmethod
     def backward(ctx, d_raw, d_ent):
         model, lib = ctx.model, L.lib()
+        _refuse_changed_params(model, ctx.params_at)               # (unconditionally: also when the stash is still this forward's)
         if lib.cfnerf_model_stash_generation(model.handle) != ctx.generation:
-            # the stash is gone: re-run the forward - which is only the SAME forward if the parameters are the ones it was taken at
-            # (torch autograd raises in this situation: an optimizer.step between the chunk backwards, a retained graph reused
-            # after an update; differentiating at the current weights instead would be silently wrong)
-            if (model.flat._version, model.params_serial) != ctx.params_at or getattr(model, "_dirty", False):
-                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: the "
-                                   "parameters of NeRF_Flows changed between this forward and its backward, and a later grad-enabled forward "
-                                   "has replaced the model's one activation stash, so the forward cannot be re-run at the weights the graph "
-                                   "was taken at (call backward() before optimizer.step(), or run one chunk per step)")
+            # the stash is gone (a later grad-enabled forward replaced it): re-run the forward - the SAME forward, the parameters
+            # being the ones it was taken at (checked above)
             model._sync()
             P, K = ctx.xf.shape[0], ctx.eps.shape[0]
             ctx.generation = _NetworkFn._forward_stash(model, ctx.xf, ctx.eps, torch.empty(P, K, 4, device=ctx.xf.device),
@@ -629,6 +642,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.model = model
         ctx.n_params = flat.numel()
         ctx.generation = lib.cfnerf_model_stash_generation(model.handle)
+        ctx.params_at = _params_token(model)
         ctx.shape = (N, 3, K)
         ctx.mark_non_differentiable(disp, raw)
         if pts is None:
@@ -639,6 +653,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb, d_disp, d_depth, d_ent, d_raw, d_pts):
         model = ctx.model
+        _refuse_changed_params(model, ctx.params_at)
         dev = model.flat.device
         grad = torch.empty(ctx.n_params, device=dev)
         d_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(ctx.shape, device=dev)

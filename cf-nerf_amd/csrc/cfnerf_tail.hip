@@ -220,10 +220,11 @@ void tail_bwd_kernel(const TailArgs A) {
             const f32x4 rv = cur.rv;
             const float alpha = cur.at[0], Tt = cur.at[1];
             const float G0 = cur.G0, G1 = cur.G1, G2 = cur.G2, Gd = cur.Gd;
-            const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
+            const SigPair s0 = t_sigmoid2(rv[0]), s1 = t_sigmoid2(rv[1]), s2 = t_sigmoid2(rv[2]);
+            const float c0 = s0.c, c1 = s1.c, c2 = s2.c;
             const float w = alpha * Tt;
-            float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
-            if (wb) g -= (G0 + G1 + G2);                                       // rgb_map += 1 - acc  (RUN:452)
+            // d loss / d w_s; white background (rgb_map += 1 - acc, RUN:452): G . c - sum G = -G . (1 - c), from the complements themselves
+            const float g = wb ? Gd * zv - (G0 * s0.omc + G1 * s1.omc + G2 * s2.omc) : (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
             const float gw = valid ? g * w : 0.f;
             const float car = carry[wave][k];
             float excl, tot;
@@ -234,9 +235,9 @@ void tail_bwd_kernel(const TailArgs A) {
             const float dalpha = g * Tt - suffix * t_rcp(xk);
             const float sg = t_sigmoid(rv[3]);                                 // softplus'
             float ga = dalpha * (1.f - alpha) * dist * sg + cE * (1.f - sg);   // + d(-mean(a - softplus a))  MOD:263
-            float gz[3] = {G0 * w * c0 * (1.f - c0) + cE * (1.f - 2.f * c0),   // + d(-mean(c - 2 softplus c)) MOD:278
-                           G1 * w * c1 * (1.f - c1) + cE * (1.f - 2.f * c1),
-                           G2 * w * c2 * (1.f - c2) + cE * (1.f - 2.f * c2)};
+            float gz[3] = {G0 * w * c0 * s0.omc + cE * (1.f - 2.f * c0),       // + d(-mean(c - 2 softplus c)) MOD:278
+                           G1 * w * c1 * s1.omc + cE * (1.f - 2.f * c1),
+                           G2 * w * c2 * s2.omc + cE * (1.f - 2.f * c2)};
             if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
 
             flows_adjoint(th, gth, gms, cur.e, a_mean, a_std, r_mean, r_std, ga, gz, cE, valid);

@@ -80,27 +80,46 @@ class RayPool:
         self.epoch = 0
 
     # ---- ONE permutation per epoch, the same on every rank ---------------------------------------------------------
+    @staticmethod
+    def _mix(seed: int, epoch: int) -> int:
+        """(seed, epoch) -> generator seed through a splitmix64-style finaliser: distinct pairs do not collide the way
+        ``seed * 1000003 + epoch`` did ((0, 1000003) and (1, 0)), and neighbouring epochs get unrelated streams."""
+        x = ((seed & 0xffffffffffffffff) * 0x9E3779B97F4A7C15 + (epoch + 1) * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff
+        x ^= x >> 30
+        x = (x * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff
+        x ^= x >> 27
+        x = (x * 0x94D049BB133111EB) & 0xffffffffffffffff
+        x ^= x >> 31
+        return x & 0x7fffffffffffffff
+
+    def _seeded_permutation(self, M, dev):
+        """Drawn ON the pool's device from a per-epoch seeded generator of that device: no 8 M-byte host permutation and upload at
+        every epoch boundary (30 MB at fern size, on every rank, stalling the host), and the same stream on every rank because every
+        rank runs the same generator algorithm on the same kind of device."""
+        g = torch.Generator(device=dev).manual_seed(self._mix(self.seed or 0, self.epoch))
+        return torch.randperm(M, device=dev, generator=g)
+
     def _permutation(self):
         M, dev = self.rays_rgb.shape[0], self.rays_rgb.device
         if self.world == 1 and self.seed is None:
             return torch.randperm(M, device=dev, generator=self.generator)
         if self.world == 1 or self.sync == "seed":
-            g = torch.Generator().manual_seed(((self.seed or 0) * 1000003 + self.epoch) & 0x7fffffffffffffff)
-            return torch.randperm(M, generator=g).to(dev)
+            return self._seeded_permutation(M, dev)
         import torch.distributed as dist
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         if self.rank == 0:
-            if self.seed is not None:
-                g = torch.Generator().manual_seed((self.seed * 1000003 + self.epoch) & 0x7fffffffffffffff)
-                idx = torch.randperm(M, generator=g).to(dev)
-            else:
-                idx = torch.randperm(M, device=dev, generator=self.generator)
+            idx = self._seeded_permutation(M, dev) if self.seed is not None else torch.randperm(M, device=dev, generator=self.generator)
         else:
             idx = torch.empty(M, dtype=torch.int64, device=dev)
-        if dist.get_backend(self.group) == "gloo" and idx.is_cuda:          # CPU tests / two test ranks on one GPU
+        backend = dist.get_backend(self.group)
+        if backend == "gloo" and idx.is_cuda:                               # CPU tests / two test ranks on one GPU
             host = idx.cpu()
             dist.broadcast(host, src=src, group=self.group)
             idx = host.to(dev)
+        elif backend == "nccl" and not idx.is_cuda:                         # a host-resident pool under an RCCL group: RCCL moves device
+            stage = idx.to(torch.device("cuda", torch.cuda.current_device()))      # buffers only, so the indices cross through this rank's GPU
+            dist.broadcast(stage, src=src, group=self.group)
+            idx = stage.to(dev)
         else:
             dist.broadcast(idx, src=src, group=self.group)
         return idx

@@ -708,6 +708,21 @@ def test_stale_stash_is_refused_and_workspace_contract():
     optimizer.zero_grad()
     out_c[0].mean().backward()
     assert torch.equal(g1, net.flat.grad)
+    # ... but not across a parameter update, even though the stash is still this forward's: the backward would differentiate the old
+    # activations against the new packed weights (torch autograd raises here too)
+    out_d = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    out_d[0].mean().backward(retain_graph=True)
+    optimizer.step()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out_d[0].mean().backward()
+    out_e = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    model.load_state_dict(model.state_dict())                                      # (writes through .data views: no torch version bump)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out_e[0].mean().backward()
+    out_f = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    TR.Trainer(net).step(H, Wd, focal, ra.to(DEV), torch.rand(16, 3, device=DEV))   # the fused Adam through the same handle
+    with pytest.raises(RuntimeError):                                              # (stale stash AND changed parameters)
+        out_f[0].mean().backward()
     # ---- workspace contract through the C ABI
     lib = L.lib()
     need_small = lib.cfnerf_workspace_bytes(C.byref(net.cfg), 8, 128, 3)
@@ -822,10 +837,11 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
           HIP masks: EVERY tensor within max(G_FLOOR, 8 x what the fp32 CPU oracle loses on the same differentiation) of its largest
           entry and of its RMS, capped at G_CAP_OTHER (G_CAP on the density path) - no sum|c| allowance, no conditioning term;
       (d) coverage, one ray at a time (first / last ray, both sides of the 4-ray workgroup and 64-ray boundaries, the middle, random
-          ones): a one-hot cotangent against the fp64 oracle on that ray alone.  Outside the density path: max(G_FLOOR, 8 x fp32 noise),
-          cap G_CAP_OTHER.  On the density path a single ray's gradient is the difference of nearly equal transmittance terms (measured
-          at K = 2: HIP up to 4.5e-3, the fp32 CPU oracle up to 7e-3 of the largest entry, either may be the worse one): 2e-2 - a dropped or
-          doubled k-part or tile of the ray is an error of >= 0.25."""
+          ones): a one-hot cotangent against the fp64 oracle on that ray alone.  Colour branch (views / h_rgb / flows_rgb / rgb base):
+          max(G_FLOOR, 8 x fp32 noise), cap G_CAP_OTHER.  On the density path a single ray's gradient is the difference of nearly equal
+          transmittance terms (measured at K = 2: HIP up to 4.5e-3, the fp32 CPU oracle up to 7e-3 of the largest entry, either may be
+          the worse one): 2e-2 there, and the fixed G_CAP_OTHER on the trunk, which carries both branches (measured <= 4.3e-5) - a dropped
+          or doubled k-part or tile of the ray is an error of >= 0.25."""
     from util_hip import G_CAP, G_CAP_OTHER, G_FLOOR, fuzz_case, hip_relu_masks
     import ctypes as C
     from cfnerf_amd import _lib as L
@@ -913,7 +929,8 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
                 assert not g_hip[off:off + cnt].any(), (i, k)
                 continue
             e = rel(g_hip[off:off + cnt].reshape(gk.shape), gk)
-            tol = 2e-2 if "alpha" in k else min(max(G_FLOOR, 8 * rel(qj[k].grad, gk)), G_CAP_OTHER)
+            # the trunk (pts_linears) feeds h_alpha_linear as well as the colour branch: it carries the density path's one-ray noise too
+            tol = 2e-2 if "alpha" in k else G_CAP_OTHER if k.startswith("pts_linears") else min(max(G_FLOOR, 8 * rel(qj[k].grad, gk)), G_CAP_OTHER)
             assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e}"
 
 
