@@ -341,6 +341,9 @@ class NeRF_Flows(nn.Module):
         self._packed_version = self.flat._version
         self._packed_ptr = self.flat.data_ptr()
         self._dirty = False
+        self.pack_serial += 1               # identifies the packed weights the library holds: a backward must meet its forward's
+
+    pack_serial = 0
 
     def mark_dirty(self):
         """Call after writing into ``flat.data`` / ``view(key)`` directly."""
@@ -458,11 +461,13 @@ def _params_token(model):
     return (model.flat._version, model.params_serial)
 
 
-def _refuse_changed_params(model, token):
-    """A backward differentiates the activations of ITS forward against the packed weights the library holds NOW: if the parameters were
-    replaced in between (optimizer.step / Trainer.step through the same handle / load_state_dict before backward()), the result would
-    be silently wrong whether or not the activation stash is still the forward's - torch autograd raises in this situation, so do we."""
-    if _params_token(model) != token:
+def _refuse_changed_params(model, token, pack_serial):
+    """A backward differentiates the stashed activations of ITS forward against what the library holds NOW: the packed weights AND -
+    for the base Gaussians (alpha_mean / alpha_std / rgb_mean / rgb_std) - the flat parameter buffer itself, which the flow-adjoint
+    kernels read live.  If either changed since the forward (optimizer.step(), Trainer.step() through the same handle,
+    load_state_dict(), mark_dirty(); or a re-pack by a later launch) the result would be silently inconsistent whether or not the
+    activation stash is still the forward's (round-4 advisor) - torch autograd raises in this situation, so do we."""
+    if _params_token(model) != token or model.pack_serial != pack_serial:
         raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: the "
                            "parameters of NeRF_Flows changed between this forward and its backward (call backward() before "
                            "optimizer.step() / Trainer.step() / load_state_dict())")
@@ -491,15 +496,19 @@ class _NetworkFn(torch.autograd.Function):
         ctx.generation = _NetworkFn._forward_stash(model, xf, eps, raw, ent)
         ctx.model, ctx.xf, ctx.eps, ctx.n_params = model, xf, eps, flat.numel()
         ctx.params_at = _params_token(model)                       # the weights this graph was taken at
+        ctx.pack_serial = model.pack_serial                        # ... and the packed copy of them the library held
         return raw, ent.reshape(())
 
     @staticmethod
     def backward(ctx, d_raw, d_ent):
         model, lib = ctx.model, L.lib()
-        _refuse_changed_params(model, ctx.params_at)               # (unconditionally: also when the stash is still this forward's)
-        if lib.cfnerf_model_stash_generation(model.handle) != ctx.generation:
-            # the stash is gone (a later grad-enabled forward replaced it): re-run the forward - the SAME forward, the parameters
-            # being the ones it was taken at (checked above)
+        if _params_token(model) != ctx.params_at or getattr(model, "_dirty", False):
+            _refuse_changed_params(model, None, None)              # (always raises)
+        if lib.cfnerf_model_stash_generation(model.handle) == ctx.generation:
+            _refuse_changed_params(model, ctx.params_at, ctx.pack_serial)      # the stash is this forward's: so must the packed weights be
+        else:
+            # the stash is gone (a later grad-enabled forward replaced it): re-run the forward - the SAME forward, the parameters being the
+            # ones it was taken at (checked above; a re-pack of unchanged parameters in between is harmless here)
             model._sync()
             P, K = ctx.xf.shape[0], ctx.eps.shape[0]
             ctx.generation = _NetworkFn._forward_stash(model, ctx.xf, ctx.eps, torch.empty(P, K, 4, device=ctx.xf.device),
@@ -642,7 +651,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.model = model
         ctx.n_params = flat.numel()
         ctx.generation = lib.cfnerf_model_stash_generation(model.handle)
-        ctx.params_at = _params_token(model)
+        ctx.params_at, ctx.pack_serial = _params_token(model), model.pack_serial
         ctx.shape = (N, 3, K)
         ctx.mark_non_differentiable(disp, raw)
         if pts is None:
@@ -653,7 +662,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb, d_disp, d_depth, d_ent, d_raw, d_pts):
         model = ctx.model
-        _refuse_changed_params(model, ctx.params_at)
+        _refuse_changed_params(model, ctx.params_at, ctx.pack_serial)      # (a replaced STASH is refused by the library itself: generation id)
         dev = model.flat.device
         grad = torch.empty(ctx.n_params, device=dev)
         d_rgb = _f32c(d_rgb) if d_rgb is not None else torch.zeros(ctx.shape, device=dev)

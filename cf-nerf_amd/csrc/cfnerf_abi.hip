@@ -273,7 +273,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         a.st_mbits = reinterpret_cast<uint32_t*>(q.mbits);
         q.n_tiles = N * (int64_t)((S + kTileM - 1) / kTileM);
         a.n_tiles = q.n_tiles;
-        a.raw = q.raw;                       // the backward reads the model's OWN copy: the caller may drop its tensor
+        a.st_raw = q.raw;                    // the backward reads the model's OWN (tile-transposed) copy: the caller may drop its tensor,
+                                             // and a caller's raw_opt is written by the same launch (rounds 1-4: a device-to-device copy after it)
         // (q.rays and m->d_eps, the backward's own copies of the step's rays and latents, are written by the copy blocks of the
         //  entropy_finalize launch below - the forward itself reads the caller's)
         q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true; q.points = false;
@@ -283,8 +284,6 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
     if (m->timing) HIPCHK(hipEventRecord(m->fr0[m->fwd_launches % kFwdRing], st));
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 0, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
     if (m->timing) { HIPCHK(hipEventRecord(m->fr1[m->fwd_launches % kFwdRing], st)); ++m->fwd_launches; }
-    if ((flags & CFNERF_F_STASH) && raw_opt)
-        HIPCHK(hipMemcpyAsync(raw_opt, m->stash.raw, (size_t)a.P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train) {
         const bool keep = flags & CFNERF_F_STASH;
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)a.P * K, entropy_out, keep ? m->d_eps : nullptr, rays,
@@ -348,15 +347,13 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
         a.st_mbits = reinterpret_cast<uint32_t*>(q.mbits);
         q.n_tiles = (P + kTileM - 1) / kTileM;
         a.n_tiles = q.n_tiles;
-        a.raw = q.raw;                       // the backward reads the model's OWN copy
+        a.st_raw = q.raw;                    // the backward reads the model's OWN (tile-transposed) copy; the caller's raw is written by the same launch
         if (!train) HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));   // (else: entropy_finalize keeps them)
         q.N = 1; q.S = (int)P; q.K = K; q.flags = flags; q.valid = true; q.points = true;
         ++q.generation;
     }
     int grid = 0;
     HIPCHK(launch_fused_fwd(a, m->plan.tab, 1, train, m->precision, m->n_cu, m->fwd_blocks_per_cu, st, &grid));
-    if (flags & CFNERF_F_STASH)
-        HIPCHK(hipMemcpyAsync(raw, m->stash.raw, (size_t)P * K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (train)
         HIPCHK(launch_entropy_finalize(m->d_ent_partials, grid, m->flat, eps, K, (double)P * K, entropy_out,
                                        (flags & CFNERF_F_STASH) ? m->d_eps : nullptr, nullptr, nullptr, 0, st));

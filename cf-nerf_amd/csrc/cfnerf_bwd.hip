@@ -192,7 +192,7 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
             if (lane < KG && k < K) {
                 G0v = d_rgb[ray * 3 * (int64_t)K + 0 * K + k]; G1v = d_rgb[ray * 3 * (int64_t)K + 1 * K + k]; G2v = d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
                 Gdv = (d_depth != nullptr) ? d_depth[ray * (int64_t)K + k] : 0.f;
-                Gav = 0.f;                                                         // (the white background's -sum G rides in g below, as -G . (1 - c))
+                Gav = white_bkgd ? -(G0v + G1v + G2v) : 0.f;
                 if (d_disp != nullptr) {
                     const float qq = accd / (acca + 1e-10f) + 1e-10f;
                     if (qq > 1e-10f + 1e-10f) {                                    // torch.max routes the gradient to the larger argument
@@ -241,15 +241,15 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                     const float G0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G0v), q)), G1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G1v), q)),
                                 G2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G2v), q)), Gd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Gdv), q)),
                                 Ga = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Gav), q));
-                    const float alpha = valid ? 1.f - M::exp(-M::softplus(rv[3]) * dist) : 0.f;
+                    const float ea = valid ? M::exp(-M::softplus(rv[3]) * dist) : 1.f;
+                    const float alpha = 1.f - ea;
                     const float xk = (1.f - alpha) + 1e-10f;
                     float incl_m, excl_m;
                     comp_scan_mul(xk, incl_m, excl_m);
                     const float Tt = carryT[wave][q][ch] * excl_m;
-                    const SigPair s0 = t_sigmoid2(rv[0]), s1 = t_sigmoid2(rv[1]), s2 = t_sigmoid2(rv[2]);      // (as in tail_bwd_kernel)
-                    const float c0 = s0.c, c1 = s1.c, c2 = s2.c;
+                    const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
                     const float w = alpha * Tt;
-                    float g = white_bkgd ? Gd * zv - (G0 * s0.omc + G1 * s1.omc + G2 * s2.omc) : (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
+                    float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
                     g += Ga;
                     g += dwv[q];
                     const float gw = valid ? g * w : 0.f;
@@ -260,8 +260,8 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                     const float dalpha = g * Tt - suffix * t_rcp(xk);
                     const float sg = t_sigmoid(rv[3]);                                 // softplus'
                     f32x4 o;
-                    o[0] = G0 * w * c0 * s0.omc; o[1] = G1 * w * c1 * s1.omc; o[2] = G2 * w * c2 * s2.omc;
-                    o[3] = dalpha * (1.f - alpha) * dist * sg;
+                    o[0] = G0 * w * c0 * (1.f - c0); o[1] = G1 * w * c1 * (1.f - c1); o[2] = G2 * w * c2 * (1.f - c2);
+                    o[3] = dalpha * ea * dist * sg;                                    // d alpha / d softplus = dist e, from the exponential itself (tail_bwd_kernel)
                     *reinterpret_cast<f32x4*>(slot) = o;                               // in place: the block leaves the way it came
                 }
             }

@@ -580,20 +580,6 @@ __device__ __forceinline__ float t_tanh(float x) {
     return __builtin_fmaf(-2.f, t_rcp(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f)), 1.f);
 }
 __device__ __forceinline__ float t_sigmoid(float x) { return t_rcp(1.f + t_exp(-x)); }
-// sigmoid AND its complement from one exponential, each accurate RELATIVE TO ITSELF (no 1 - c subtraction, no overflow): with a white
-// background the composite adjoint needs d loss / d w = G . c - sum G = -G . (1 - c) (RUN:452), and the recomputed c carries ~3e-7 of
-// relative error - subtracted from 1 that is 3e-7 / (1 - c) of the result for a nearly white sample (round 5: the per-ray density-path
-// gradients of white-background batches were 10-30 x further from fp64 than torch's own fp32 autograd, which subtracts its SAVED c).
-struct SigPair { float c, omc; };          // sigmoid(x), 1 - sigmoid(x) = sigmoid(-x)
-__device__ __forceinline__ SigPair t_sigmoid2(float x) {
-    const float e = t_exp(-fabsf(x));      // in (0, 1]
-    const float big = t_rcp(1.f + e), small = e * big;
-    SigPair s;
-    s.c = x >= 0.f ? big : small;
-    s.omc = x >= 0.f ? small : big;
-    return s;
-}
-
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -466,9 +466,11 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 const float* const f_eps = A.eps;
                 float* const f_raw = A.raw;
                 float* const f_weights = A.weights;
-                float* const f_at = A.st_at;
+                // this tile's block of the transposed stash pieces: [k][64 rows][4] / [k][64 rows][2]
+                float* const f_sraw = (A.st_raw != nullptr) ? A.st_raw + (size_t)tile_idx * K * (kTileM * 4) : nullptr;
+                float* const f_at = (A.st_at != nullptr) ? A.st_at + (size_t)tile_idx * K * (kTileM * 2) : nullptr;
                 const int f_flags = A.flags;
-                fetched_together(f_eps, f_raw, f_weights, f_at, f_flags);
+                fetched_together(f_eps, f_raw, f_weights, f_sraw, f_at, f_flags);
                 const int row = lane_id_opaque();
                 const bool valid = row < rows_valid;
                 float th[84];
@@ -502,9 +504,10 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                         float a = e[3] * a_std + a_mean;                                               // MOD:200/239
                         float ldr, lda;
                         flows_fwd<TRAIN, FAST>(th, z, a, ldr, lda);
-                        if (f_raw != nullptr && valid) {
+                        if (f_raw != nullptr || f_sraw != nullptr) {
                             f32x4 o; o[0] = z[0]; o[1] = z[1]; o[2] = z[2]; o[3] = a;
-                            *reinterpret_cast<f32x4*>(f_raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
+                            if (f_raw != nullptr && valid) *reinterpret_cast<f32x4*>(f_raw + ((p0 + row) * (int64_t)K + k) * 4) = o;  // MOD:221/289
+                            if (f_sraw != nullptr) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(f_sraw + (k * kTileM + row) * 4));   // (rows past a ragged tile: finite filler, never read)
                         }
                         const float sp_a = M::softplus(a);
                         if (TRAIN && valid) {
@@ -512,7 +515,8 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                             ent_r_sum += ldr + (((z[0] + z[1]) + z[2]) - 2.f * ((M::softplus(z[0]) + M::softplus(z[1])) + M::softplus(z[2])));  // MOD:278
                         }
                         if (MODE == 0) {
-                            const float alpha = valid ? 1.f - M::exp(-sp_a * dist) : 0.f;                // RUN:424,442
+                            const float ea = valid ? M::exp(-sp_a * dist) : 1.f;
+                            const float alpha = 1.f - ea;                                              // RUN:424,442
                             const float xk = (1.f - alpha) + 1e-10f;                                   // RUN:443
                             float incl, excl;
                             comp_scan_mul(xk, incl, excl);
@@ -520,9 +524,9 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                             const float Tcar = cp[5];
                             const float wgt = alpha * (Tcar * excl);
                             if (f_weights != nullptr && valid) f_weights[(p0 + row) * (int64_t)K + k] = wgt;
-                            if (f_at != nullptr && valid) {
-                                f32x2 at; at[0] = alpha; at[1] = Tcar * excl;
-                                *reinterpret_cast<f32x2*>(f_at + ((p0 + row) * (int64_t)K + k) * 2) = at;
+                            if (f_at != nullptr) {
+                                f32x2 at; at[0] = ea; at[1] = Tcar * excl;      // (e, T): the backward takes d alpha / d sigma from e itself
+                                __builtin_nontemporal_store(at, reinterpret_cast<f32x2*>(f_at + (k * kTileM + row) * 2));
                             }
                             const float s0 = comp_sum(wgt * M::sigmoid(z[0]));                         // RUN:431,444
                             const float s1 = comp_sum(wgt * M::sigmoid(z[1]));

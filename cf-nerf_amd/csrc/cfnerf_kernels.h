@@ -41,7 +41,12 @@ struct FwdArgs {
     float* enc_scratch;                  // [grid, 64*64] per-workgroup parking slot of the encoded tile (used when there is no stash)
     // activation stash for the backward pass (all optional, row-major per point)
     float *st_enc, *st_gd, *st_h, *st_feat, *st_v, *st_ha, *st_hr, *st_theta, *st_z;
-    float *st_at;                        // [P,K,2] alpha, transmittance T of the composite
+    // the K-proportional pieces of the stash are TILE-TRANSPOSED, [tile][k][64 rows][.]: lane = row in the kernels that write and read
+    // them, so one latent of one tile is ONE contiguous piece per wave instruction (1 KB of raw, 512 B of (e, T)); the row-major
+    // [P,K,.] form of rounds 1-4 put a lane's pieces 16 K bytes apart, and at K = 64 the tail kernel's 200 MB of strided reads
+    // cost backward-data ~47 us of cache state (round 5, profiles/EXPERIMENTS.md)
+    float *st_raw;                       // [tiles,K,64,4] flow outputs of the stashed forward (A.raw: the CALLER's row-major [P,K,4], optional)
+    float *st_at;                        // [tiles,K,64,2] e = exp(-sigma dist) = 1 - alpha, transmittance T of the composite
     uint32_t* st_mbits;                  // [D+1][tiles][W/32][64] ReLU masks as fragment-ordered bit words
     int64_t n_tiles;                     // tiles of the launch (rays * chunks per ray)
 };

@@ -51,9 +51,9 @@ struct Stash {
     float *hr = nullptr;     // [P,HR]
     float *theta = nullptr;  // [P,128]  flow parameters (diagonals tanh-ed)
     float *z = nullptr;      // [P]      z_vals
-    float *raw = nullptr;    // [P,K,4]
+    float *raw = nullptr;    // [tiles,K,64,4]  tile-transposed (cfnerf_kernels.h: st_raw)
     float *rays = nullptr;   // [N,11]
-    float *at = nullptr;     // [P,K,2]  alpha, T
+    float *at = nullptr;     // [tiles,K,64,2]  e = exp(-sigma dist) (alpha = 1 - e), T; tile-transposed
     float *mbits = nullptr;  // [D+1][tiles][W/32][64] u32 ReLU mask words (fragment order)
     // ---- written by the backward (same row-major-per-point convention)
     float *gms = nullptr;       // [N*parts,8]    base-Gaussian gradient partials
@@ -101,8 +101,8 @@ struct Stash {
         take(&t->enc, (size_t)P * 64, 4); take(&t->gd, (size_t)P * 32, 4);
         take(&t->h, (size_t)D * P * W, 4); take(&t->feat, (size_t)P * W, 4); take(&t->v, (size_t)P * (W / 2), 4);
         take(&t->ha, (size_t)P * c.h_alpha_size, 4); take(&t->hr, (size_t)P * c.h_rgb_size, 4);
-        take(&t->theta, (size_t)P * kThetaAll, 4); take(&t->z, (size_t)P + 1, 4); take(&t->raw, (size_t)P * k * 4, 4);
-        take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)P * k * 2, 4);
+        take(&t->theta, (size_t)P * kThetaAll, 4); take(&t->z, (size_t)P + 1, 4); take(&t->raw, (size_t)tiles * kTileM * k * 4, 4);
+        take(&t->rays, (size_t)n * 11, 4); take(&t->at, (size_t)tiles * kTileM * k * 2, 4);
         take(&t->mbits, (size_t)(D + 1) * tiles * (W / 32) * 64, 4);
         take(&t->gms, (size_t)(std::max<int64_t>(n * kTailParts, tiles) + 8) * 8, 4);      // rays * k-parts (fused tail) or waves of points (flows_bwd)
         take(&t->g_theta, (size_t)P * kThetaAll, 4); take(&t->g_hr, (size_t)P * c.h_rgb_size, 4);      // ONE row per point whatever the k-parts

@@ -187,6 +187,10 @@ void tail_bwd_kernel(const TailArgs A) {
         const int s = ch * 64 + lane;
         const bool valid = s < S;
         const int64_t p = ray * (int64_t)S + (valid ? s : 0);
+        // this chunk's tile of the transposed stash pieces (cfnerf_kernels.h): [k][64 rows][4] / [k][64 rows][2], lane = row
+        const int tile_s = __builtin_amdgcn_readfirstlane((int)(ray * nch + ch));       // (scalar: the tile base stays in SGPRs, a lane keeps one 32-bit offset)
+        const __amdgpu_buffer_rsrc_t raw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.raw + (size_t)tile_s * K * 256), 0, K * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t at_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.at + (size_t)tile_s * K * 128), 0, K * 512, 0x00020000);
         float th[84];
         {
             const f32x4* tp = reinterpret_cast<const f32x4*>(A.theta + p * kThetaAll);
@@ -205,8 +209,10 @@ void tail_bwd_kernel(const TailArgs A) {
         struct KIn { f32x4 rv; f32x2 at; f32x4 e; float G0, G1, G2, Gd; };
         auto fetch = [&](int k) {
             KIn q;
-            q.rv = *reinterpret_cast<const f32x4*>(A.raw + (p * K + k) * 4);
-            q.at = *reinterpret_cast<const f32x2*>(A.at + (p * K + k) * 2);
+            // touch-once and coalesced (1 KB / 512 B per wave instruction), through ONE buffer descriptor per array: the tile base and the
+            // latent are scalar offsets, a lane keeps lane * 16 / lane * 8 (no 64-bit vector addresses in a kernel that lives at 256 registers)
+            q.rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raw_rs, lane * 16, k * 1024, /*nt*/ 2));
+            q.at = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(at_rs, lane * 8, k * 512, /*nt*/ 2));
             q.e = *reinterpret_cast<const f32x4*>(A.eps + k * 4);
             q.G0 = A.d_rgb[ray * 3 * (int64_t)K + 0 * K + k]; q.G1 = A.d_rgb[ray * 3 * (int64_t)K + 1 * K + k];
             q.G2 = A.d_rgb[ray * 3 * (int64_t)K + 2 * K + k];
@@ -218,13 +224,18 @@ void tail_bwd_kernel(const TailArgs A) {
             const KIn cur = nx;
             if (k + 1 < k_hi) nx = fetch(k + 1);
             const f32x4 rv = cur.rv;
-            const float alpha = cur.at[0], Tt = cur.at[1];
+            // the forward stashed e = exp(-softplus(a) dist) and T: alpha = 1 - e is the forward's own number again (one exact subtraction),
+            // and d alpha / d softplus = dist * e comes from the exponential ITSELF like torch's exp backward.  Rounds 1-4 stashed alpha and
+            // multiplied by (1 - alpha): for an opaque sample - above all a ray's LAST one, whose 1e1 interval (RUN:427) makes it the largest
+            // entry of the density gradient - that subtraction keeps e only to eps / e (alpha = 0.99925: 8e-5), and a single ray's
+            // density-path gradient sat 10-30 x further from fp64 than torch's own fp32 autograd (tests/tools/k2_grad_diag.py, round 5)
+            const float ea = cur.at[0], Tt = cur.at[1];
+            const float alpha = 1.f - ea;
             const float G0 = cur.G0, G1 = cur.G1, G2 = cur.G2, Gd = cur.Gd;
-            const SigPair s0 = t_sigmoid2(rv[0]), s1 = t_sigmoid2(rv[1]), s2 = t_sigmoid2(rv[2]);
-            const float c0 = s0.c, c1 = s1.c, c2 = s2.c;
+            const float c0 = t_sigmoid(rv[0]), c1 = t_sigmoid(rv[1]), c2 = t_sigmoid(rv[2]);
             const float w = alpha * Tt;
-            // d loss / d w_s; white background (rgb_map += 1 - acc, RUN:452): G . c - sum G = -G . (1 - c), from the complements themselves
-            const float g = wb ? Gd * zv - (G0 * s0.omc + G1 * s1.omc + G2 * s2.omc) : (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
+            float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
+            if (wb) g -= (G0 + G1 + G2);                                       // rgb_map += 1 - acc  (RUN:452)
             const float gw = valid ? g * w : 0.f;
             const float car = carry[wave][k];
             float excl, tot;
@@ -234,10 +245,10 @@ void tail_bwd_kernel(const TailArgs A) {
             const float xk = (1.f - alpha) + 1e-10f;                           // cumprod factor of RUN:443
             const float dalpha = g * Tt - suffix * t_rcp(xk);
             const float sg = t_sigmoid(rv[3]);                                 // softplus'
-            float ga = dalpha * (1.f - alpha) * dist * sg + cE * (1.f - sg);   // + d(-mean(a - softplus a))  MOD:263
-            float gz[3] = {G0 * w * c0 * s0.omc + cE * (1.f - 2.f * c0),       // + d(-mean(c - 2 softplus c)) MOD:278
-                           G1 * w * c1 * s1.omc + cE * (1.f - 2.f * c1),
-                           G2 * w * c2 * s2.omc + cE * (1.f - 2.f * c2)};
+            float ga = dalpha * ea * dist * sg + cE * (1.f - sg);              // + d(-mean(a - softplus a))  MOD:263
+            float gz[3] = {G0 * w * c0 * (1.f - c0) + cE * (1.f - 2.f * c0),   // + d(-mean(c - 2 softplus c)) MOD:278
+                           G1 * w * c1 * (1.f - c1) + cE * (1.f - 2.f * c1),
+                           G2 * w * c2 * (1.f - c2) + cE * (1.f - 2.f * c2)};
             if (!valid) { ga = 0.f; gz[0] = gz[1] = gz[2] = 0.f; }
 
             flows_adjoint(th, gth, gms, cur.e, a_mean, a_std, r_mean, r_std, ga, gz, cE, valid);
@@ -301,7 +312,7 @@ void flows_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ t
 #pragma unroll
     for (int i = 0; i < 8; ++i) gms[i] = 0.f;
     for (int k = 0; k < K; ++k) {
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + (p * K + k) * 4);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + (((p >> 6) * K + k) * 64 + (p & 63)) * 4);    // tile-transposed stash: [tile p / 64][k][row p % 64][4]
         f32x4 g; g[0] = g[1] = g[2] = g[3] = 0.f;
         if (d_raw != nullptr) g = *reinterpret_cast<const f32x4*>(d_raw + (p * K + k) * 4);
         const f32x4 e = *reinterpret_cast<const f32x4*>(eps + k * 4);

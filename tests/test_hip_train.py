@@ -690,7 +690,7 @@ def test_stale_stash_is_refused_and_workspace_contract():
     import ctypes as C
     from cfnerf_amd import _lib as L
     cfg = O.OracleCfg(netwidth=64, K_samples=3)
-    _, kw_train, _, model, p, optimizer = build_model(cfg, 5)
+    _, kw_train, kw_test, model, p, optimizer = build_model(cfg, 5)
     net = model.module
     rng = np.random.default_rng(3)
     ra, (H, Wd, focal) = fern_rays(rng, 16)
@@ -709,8 +709,10 @@ def test_stale_stash_is_refused_and_workspace_contract():
     out_c[0].mean().backward()
     assert torch.equal(g1, net.flat.grad)
     # ... but not across a parameter update, even though the stash is still this forward's: the backward would differentiate the old
-    # activations against the new packed weights (torch autograd raises here too)
+    # activations against the new base Gaussians (the flow-adjoint kernels read them from the flat buffer) and - once anything re-packed -
+    # the new weights; torch autograd raises here too (round-4 advisor: the guard used to sit on the re-run path only)
     out_d = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    optimizer.zero_grad()
     out_d[0].mean().backward(retain_graph=True)
     optimizer.step()
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
@@ -720,9 +722,15 @@ def test_stale_stash_is_refused_and_workspace_contract():
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out_e[0].mean().backward()
     out_f = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
-    TR.Trainer(net).step(H, Wd, focal, ra.to(DEV), torch.rand(16, 3, device=DEV))   # the fused Adam through the same handle
-    with pytest.raises(RuntimeError):                                              # (stale stash AND changed parameters)
+    TR.Trainer(net).step(H, Wd, focal, ra.to(DEV), torch.rand(16, 3, device=DEV))   # the fused Adam through the same handle: re-packs AND replaces the stash
+    with pytest.raises(RuntimeError):
         out_f[0].mean().backward()
+    out_g = cfnerf_amd.render(H, Wd, focal, rays=rb.to(DEV), **kw_train)
+    with torch.no_grad():
+        cfnerf_amd.render(H, Wd, focal, rays=ra.to(DEV), **kw_test)              # an eval render in between is harmless: nothing changed, no stash taken
+    optimizer.zero_grad()
+    out_g[0].mean().backward()
+    assert torch.isfinite(net.flat.grad).all()
     # ---- workspace contract through the C ABI
     lib = L.lib()
     need_small = lib.cfnerf_workspace_bytes(C.byref(net.cfg), 8, 128, 3)
@@ -839,9 +847,10 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
       (d) coverage, one ray at a time (first / last ray, both sides of the 4-ray workgroup and 64-ray boundaries, the middle, random
           ones): a one-hot cotangent against the fp64 oracle on that ray alone.  Colour branch (views / h_rgb / flows_rgb / rgb base):
           max(G_FLOOR, 8 x fp32 noise), cap G_CAP_OTHER.  On the density path a single ray's gradient is the difference of nearly equal
-          transmittance terms (measured at K = 2: HIP up to 4.5e-3, the fp32 CPU oracle up to 7e-3 of the largest entry, either may be
-          the worse one): 2e-2 there, and the fixed G_CAP_OTHER on the trunk, which carries both branches (measured <= 4.3e-5) - a dropped
-          or doubled k-part or tile of the ray is an error of >= 0.25."""
+          transmittance terms (measured at K = 2: HIP up to 4.4e-2 where the fp32 CPU oracle is at 8e-3, typically 1e-4 .. 3e-3 against
+          1e-5 .. 2e-3; either may be the worse one): max(2e-2, 10 x the fp32 CPU oracle's own error on that ray), never above 0.1, and
+          the fixed G_CAP_OTHER on the trunk, which carries both branches (measured <= 4.3e-5) - a dropped or doubled k-part or tile of
+          the ray is an error of >= 0.25."""
     from util_hip import G_CAP, G_CAP_OTHER, G_FLOOR, fuzz_case, hip_relu_masks
     import ctypes as C
     from cfnerf_amd import _lib as L
@@ -930,8 +939,10 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
                 continue
             e = rel(g_hip[off:off + cnt].reshape(gk.shape), gk)
             # the trunk (pts_linears) feeds h_alpha_linear as well as the colour branch: it carries the density path's one-ray noise too
-            tol = 2e-2 if "alpha" in k else G_CAP_OTHER if k.startswith("pts_linears") else min(max(G_FLOOR, 8 * rel(qj[k].grad, gk)), G_CAP_OTHER)
-            assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e}"
+            n32 = rel(qj[k].grad, gk)
+            tol = (min(max(2e-2, 10 * n32), 0.1) if "alpha" in k else G_CAP_OTHER if k.startswith("pts_linears")
+                   else min(max(G_FLOOR, 8 * n32), G_CAP_OTHER))
+            assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e} (fp32 CPU oracle on this ray: {n32:.1e})"
 
 
 def test_one_hot_cotangent_reaches_every_ray_at_production_batch():
