@@ -278,6 +278,8 @@ int cfnerf_render_fwd(cfnerf_model* m, const float* rays, const float* t_vals, c
         // (q.rays and m->d_eps, the backward's own copies of the step's rays and latents, are written by the copy blocks of the
         //  entropy_finalize launch below - the forward itself reads the caller's)
         q.N = N; q.S = S; q.K = K; q.flags = flags; q.valid = true; q.points = false;
+        q.q4 = (S % kTileM == 0) && m->precision == 0;      // whole tiles, fp32 mode: the wide streams take the Q4 layout (cfnerf_device.h)
+        a.q4 = q.q4;
         ++q.generation;                      // this forward now owns the one stash: older backward passes are refused
     }
     int grid = 0;
@@ -350,6 +352,8 @@ int cfnerf_network_fwd(cfnerf_model* m, const float* x, const float* eps, int64_
         a.st_raw = q.raw;                    // the backward reads the model's OWN (tile-transposed) copy; the caller's raw is written by the same launch
         if (!train) HIPCHK(hipMemcpyAsync(m->d_eps, eps, (size_t)K * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));   // (else: entropy_finalize keeps them)
         q.N = 1; q.S = (int)P; q.K = K; q.flags = flags; q.valid = true; q.points = true;
+        q.q4 = (P % kTileM == 0) && m->precision == 0;
+        a.q4 = q.q4;
         ++q.generation;
     }
     int grid = 0;

@@ -29,6 +29,7 @@ struct BwdArgs {
     const uint32_t* mbits;                                // [D+1][tiles][W/32][64] ReLU masks (fragment-ordered bit words)
     int64_t n_tiles; int32_t S;                           // same tiling as the forward: tile = ray * chunks_per_ray + chunk
     float* dbp;                                           // [n_wg, nb] bias-gradient partials
+    int32_t q4;                                           // 1: g_h / g_feat leave in the Q4 layout (cfnerf_device.h), as the forward wrote h
     int32_t db_h, db_feat, db_v, db_ha, db_hr, db_theta;  // column offsets inside a dbp row
 };
 
@@ -48,6 +49,7 @@ struct DwTile {
     int32_t gk, wk;                                       // small kernel: waves along k, k-tiles per wave (GN = 8 / gk);
                                                           // big kernel: gk = wave arrangement (0: 2 x 4, 1: 1 x 8 for N <= 128)
     int32_t nsplit;                                       // point splits of this tile (blocks per tile)
+    int32_t lay;                                          // operand layouts: bit 0 = dY, bit 1 = X is a Q4 stream (cfnerf_device.h), else row-major
     int32_t row_f;                                        // 0, or (theta-head tiles) the model's n_flows: dY column 4 b + f is destination row b F + f of
                                                           // the concatenated heads, columns with f >= n_flows are dropped (cfnerf_layout.h)
 };
@@ -77,6 +79,7 @@ struct BwdPlan {
     DwHost host[2];                                       // double-buffered: a rebuild never waits for the previous upload
     int cur = 0;                                          // the set the device copies were made from
     uint64_t bind_serial = ~0ull;                         // Stash::bind_serial the descriptors were built for
+    bool q4 = false;                                      // ... and the layout of the wide streams (Stash::q4) they describe
     int n_blocks_wide = 0;                                // blocks[0, n_blocks_wide): 2 x 4 tiles; the rest: 1 x 8 tiles
     hipEvent_t ev_early = nullptr;                        // recorded once the "early" tensors' gradients are final
     std::vector<int64_t> early_off, early_cnt;            // flat ranges of grad_flat that are final at ev_early (merged, sorted)

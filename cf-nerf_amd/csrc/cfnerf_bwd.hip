@@ -310,13 +310,15 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<NTW>& e, int nt_total, int n
 // acc (masked) -> LDS tile, global dY matrix, per-workgroup bias partials.  The dY slab goes out through a buffer
 // descriptor over the tile's valid rows (scalar row offsets, ragged rows dropped by the bounds check: see slab_store);
 // the mask is applied with one v_bfe_i32 + one v_and per element (relu_bit_apply).
-template <int NTW, int PREC, bool RAGGED>
+// Q4 (whole tiles only, never RAGGED): the four rows of a group leave as ONE 16-byte store per lane, 1 KB contiguous per instruction,
+// in the fragment-quad layout of cfnerf_device.h - 16 vector-memory instructions per n-tile instead of 64 (-3.5 % on this kernel).
+template <int NTW, int PREC, bool RAGGED, bool Q4>
 __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
                                                float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
                                                int rows_valid) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
-    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, rows_valid, gld);
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, Q4 ? kTileM : rows_valid, gld);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = nt0 + j * nts;
@@ -326,6 +328,7 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
         const int voff = (rbase * gld + col) * 4;
         const uint32_t mb = e.mb[j];
         float csum = 0.f;
+        [[maybe_unused]] u32x4 q4v;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -336,8 +339,15 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
                 if (RAGGED && rr + rbase >= rows_valid) v0 = 0.f;      // rows past a ragged tile hold garbage activations
                 if (RAGGED && rr + 1 + rbase >= rows_valid) v1 = 0.f;
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, col, v0, v1);
-                slab_store(sink, voff, rr * gld * 4, v0);
-                slab_store(sink, voff, (rr + 1) * gld * 4, v1);
+                if (!Q4) {
+                    slab_store(sink, voff, rr * gld * 4, v0);
+                    slab_store(sink, voff, (rr + 1) * gld * 4, v1);
+                } else if ((r & 3) == 0) {
+                    q4v[0] = __float_as_uint(v0); q4v[1] = __float_as_uint(v1);
+                } else {
+                    q4v[2] = __float_as_uint(v0); q4v[3] = __float_as_uint(v1);
+                    __builtin_amdgcn_raw_buffer_store_b128(q4v, sink, lane * 16, __builtin_amdgcn_readfirstlane(q4_piece(i, nt, r >> 2, gld >> 5)), /*nt*/ 2);
+                }
                 csum += v0; csum += v1;
             }
         csum += __shfl_xor(csum, 32, 64);
@@ -349,9 +359,10 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
 template <int NTW, int PREC>
 __device__ __forceinline__ void store_bwd(const f32x16 (&acc)[2][NTW], const EpiPre<NTW>& e, int nt_total, int nt0, int nts,
                                           float* lds_dst, int ld, float* __restrict__ gdst, int gld, float* __restrict__ dbp,
-                                          int rows_valid) {
-    if (rows_valid >= 64) store_bwd_impl<NTW, PREC, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
-    else                  store_bwd_impl<NTW, PREC, true>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
+                                          int rows_valid, bool q4 = false) {
+    if (q4 && PREC == PREC_F32) store_bwd_impl<NTW, PREC, false, PREC == PREC_F32>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
+    else if (rows_valid >= 64)  store_bwd_impl<NTW, PREC, false, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
+    else                        store_bwd_impl<NTW, PREC, true, false>(acc, e, nt_total, nt0, nts, lds_dst, ld, gdst, gld, dbp, rows_valid);
 }
 
 // the kernarg segment of bwd_data_kernel as one struct (see fused_fwd_kernel)
@@ -490,7 +501,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             epi_prefetch<NTW>(e, T.bt_vf.nt, wave, kWaves, nullptr, dbp + A.db_feat, first);
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_vf), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
-            store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, T.bt_vf.nt, wave, kWaves, act, LD, A.g_feat + p0 * W, W, dbp + A.db_feat, rows_valid, A.q4 != 0);
             __syncthreads();
         }
         // ---- 4. dh_{D-1} = (dfeature * F + dh_alpha * A) . relu'(h_{D-1})
@@ -503,7 +514,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ft), wave, kWaves, wp, wp16, act, LD);
             mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_ha), wave, kWaves, wp, wp16, hs, HLD);
             __syncthreads();
-            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(D - 1) * P + p0) * W, W, dbp + A.db_h + (D - 1) * W, rows_valid, A.q4 != 0);
             __syncthreads();
         }
         // ---- 5. trunk: dh_{l-1} = (dh_l * W_l[:, h part]) . relu'(h_{l-1})
@@ -526,7 +537,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
                 mma_any<NTW, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_trunk[l]), wave, kWaves, wp, wp16, act, LD);
             }
             __syncthreads();
-            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid);
+            store_bwd<NTW, PREC>(acc, e, NT, wave, kWaves, act, LD, A.g_h + ((size_t)(l - 1) * P + p0) * W, W, dbp + A.db_h + (l - 1) * W, rows_valid, A.q4 != 0);
             __syncthreads();
         }
     }
@@ -787,13 +798,120 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
     }
 }
 
-// ONE launch for both arrangements: every workgroup has the same resource footprint (one per CU), so any mix of 2 x 4
+// The same tile with BOTH operands in the Q4 layout (cfnerf_device.h; fp32 mode, whole tiles).  A 32-point stage of an operand is
+// ONE contiguous run of (n-tiles x 4) 1-KB pieces in memory - the LDS-DMA copies it verbatim, no column slicing - and the MFMA loop
+// takes a piece as it is: per group g (8 points) one ds_read_b128 per 32-column tile and lane, four k-steps each (lane half h: points
+// 8 g + 4 h + e for A and B alike).  Wave arrangement as above: 2 x 4 (wave = n-tiles 4 wn .. 4 wn + 3 x k-tiles 2 wk, 2 wk + 1) or, for
+// N <= 128, 1 x 8 (n-tiles 0 .. 3 x k-tile wk).  The output tile is natural (no interleaving): dW[n0 + 32 tn' + frag_row][k0 + 32 tk' + lane & 31].
+template <int ARR>
+__device__ __attribute__((noinline)) void dw_big_body_q4(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
+                                                         float* __restrict__ partials_, int64_t n_params_) {
+    const DwTile* __restrict__ tiles = uniform_ptr(tiles_);
+    const DwBlock* __restrict__ blocks = uniform_ptr(blocks_);
+    float* __restrict__ partials = uniform_ptr(partials_);
+    const int64_t n_params = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)n_params_ >> 32)) << 32) |
+                                       __builtin_amdgcn_readfirstlane((unsigned)n_params_));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool arr1 = ARR == 1;
+    const DwBlock blk = blocks[blockIdx.x];
+    const DwTile t = tiles[blk.tile];
+    const int lane = lane_id_opaque(), wave = wave_id();
+    const int wn = arr1 ? 0 : wave >> 2, wk = arr1 ? wave : wave & 3;
+    const int rows_u = __builtin_amdgcn_readfirstlane((int)(blk.pe - blk.pb));       // a multiple of 32 (whole half-tiles)
+    const int ldY = __builtin_amdgcn_readfirstlane(t.ldY), ldX = __builtin_amdgcn_readfirstlane(t.ldX);
+    // staged n-tiles of the two operands: [n0, n0 + 256) of dY's N columns, [k0, k0 + 256) of X's K columns
+    const int ca = __builtin_amdgcn_readfirstlane(min(8, (t.N - t.n0 + 31) >> 5)), cb = __builtin_amdgcn_readfirstlane(min(8, (t.K - t.k0 + 31) >> 5));
+    // a half-tile (32 points) of a C-column Q4 stream is C * 32 floats: the block's first stage starts where its row-major rows would
+    const float* baseY = t.dY + blk.pb * t.ldY + t.n0 * 32;
+    const float* baseX = t.X + blk.pb * t.ldX + t.k0 * 32;
+    const i32x4 da = ds_rsrc(baseY, rows_u * ldY * 4), db = ds_rsrc(baseX, rows_u * ldX * 4);
+    const unsigned sa_step = (unsigned)ldY * 128u, sb_step = (unsigned)ldX * 128u;       // bytes per stage: 32 points x C columns
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned kOpBytes = 2u * kDwRows * 256u * 4u;                              // both buffers of one operand
+    int dma_stage = 0;
+    // piece m = wave + 8 q (q = 0 .. 3) of an operand's stage: 1 KB at m * 1024 in memory and in LDS alike
+    auto issue_h = [&](int buf, int q, int which) {
+        const unsigned m = wave_u + 8u * (unsigned)q;
+        if (which == 0) { if ((int)m < 4 * ca) ds_dma16(da, lds0 + (unsigned)buf * (kDwRows * 1024u) + m * 1024u, (unsigned)lane * 16u + m * 1024u, (unsigned)__builtin_amdgcn_readfirstlane(dma_stage) * sa_step); }
+        else            { if ((int)m < 4 * cb) ds_dma16(db, lds0 + kOpBytes + (unsigned)buf * (kDwRows * 1024u) + m * 1024u, (unsigned)lane * 16u + m * 1024u, (unsigned)__builtin_amdgcn_readfirstlane(dma_stage) * sb_step); }
+    };
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { issue_h(buf, q, 0); issue_h(buf, q, 1); }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int jn = 4 * wn, jk = arr1 ? wk : 2 * wk;              // first n-tile / k-tile of this wave inside the staged tiles
+    const bool active = jn < ca && jk < cb;                      // wave-uniform
+    const float* a_rd = smem + (jn * 4) * 256 + lane * 4;                                // piece (tile, g) = (tile * 4 + g) * 256 floats
+    const float* b_rd = smem + (kOpBytes / 4) + (jk * 4) * 256 + lane * 4;
+    issue(0); dma_stage = 1;
+    int buf = 0;
+    for (int p = 0; p < rows_u; p += kDwRows) {
+        const bool more = p + kDwRows < rows_u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the current stage have landed
+        __syncthreads();                                         // ... everyone's have, and everyone is done reading the other buffer
+        if (more && !active) issue(buf ^ 1);
+        if (active) {
+            const float* ar = a_rd + buf * (kDwRows * 256);
+            const float* br = b_rd + buf * (kDwRows * 256);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 av[4], bv[2];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) av[tn] = *reinterpret_cast<const f32x4*>(ar + (tn * 4 + g) * 256);
+                bv[0] = *reinterpret_cast<const f32x4*>(br + g * 256);
+                if (!arr1) bv[1] = *reinterpret_cast<const f32x4*>(br + (4 + g) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        acc[tn][0] = CFN_MFMA(av[tn][e], bv[0][e], acc[tn][0]);
+                        if (!arr1) acc[tn][1] = CFN_MFMA(av[tn][e], bv[1][e], acc[tn][1]);
+                    }
+                    // the next stage's pieces go out one at a time between the first MFMA groups (a burst in front of them keeps both waves of a SIMD off the matrix pipe)
+                    if (more && g < 2) issue_h(buf ^ 1, (g * 4 + e) >> 1, (g * 4 + e) & 1);
+                }
+            }
+        }
+        ++dma_stage;
+        buf ^= 1;
+    }
+    if (active) {
+        gf_ptr out = (gf_ptr)(partials + (size_t)blk.split * n_params);
+        const int kcol = t.k0 + 32 * jk + (lane & 31);
+        gf_ptr o = out + ((size_t)t.seg_dst[0] + t.dst_col + kcol);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = t.n0 + 32 * (jn + tn) + frag_row(r, lane);
+                if (n < t.N) {
+                    gf_ptr row = o + (size_t)n * t.dst_ld;
+                    if (kcol < t.K) row[0] = acc[tn][0][r];
+                    if (!arr1 && kcol + 32 < t.K) row[32] = acc[tn][1][r];
+                }
+            }
+    }
+}
+
+// ONE launch for all arrangements: every workgroup has the same resource footprint (one per CU), so any mix of 2 x 4
 // and 1 x 8 blocks fills the chip one block per CU with no second stream and no placement assumptions.
 template <int PREC>
 __global__ __launch_bounds__(kDwThreads, 2)
 void dw_big_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict__ blocks, float* __restrict__ partials, int64_t n_params) {
-    if (tiles[blocks[blockIdx.x].tile].gk == 1) dw_big_body<PREC, 1>(tiles, blocks, partials, n_params);
-    else                                        dw_big_body<PREC, 0>(tiles, blocks, partials, n_params);
+    const DwTile& t = tiles[blocks[blockIdx.x].tile];
+    if (PREC == PREC_F32 && t.lay == 3) {
+        if (t.gk == 1) dw_big_body_q4<1>(tiles, blocks, partials, n_params);
+        else           dw_big_body_q4<0>(tiles, blocks, partials, n_params);
+    } else if (t.gk == 1) dw_big_body<PREC, 1>(tiles, blocks, partials, n_params);
+    else                  dw_big_body<PREC, 0>(tiles, blocks, partials, n_params);
 }
 
 // ---- 4b. small jobs (K or N well below 256: encodings, heads, flow heads).  The 8 waves of a workgroup each own ONE
@@ -831,6 +949,10 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
     // loader: piece j = wave, wave + 8, wave + 16 of the stage's nI = (a_ld + b_ld) / 8 pieces; pieces [0, nA) carry dY
     const int nA = a_ld >> 3, nI = (a_ld + b_ld) >> 3;
     const int n_w = (nI - wave + 7) >> 3;                     // pieces of this wave per stage: 1..3 (nI >= 8)
+    // An operand in the Q4 layout (DwTile::lay; cfnerf_device.h) needs no slicing: the 32-point stage of its staged n-tiles is ONE
+    // contiguous run of 1-KB pieces, (n-tile, group g) = piece tile * 4 + g, which starts n0 * 32 floats into the half-tile - and the
+    // half-tile where the block's row-major rows would start (32 points x C columns either way), so base, size and stage step are shared.
+    const bool qa = (t.lay & 1) != 0, qb = (t.lay & 2) != 0;  // wave-uniform
     unsigned voff[kDsSlots], loff[kDsSlots];
     bool is_a[kDsSlots];
 #pragma unroll
@@ -842,6 +964,7 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
         const int row = c / cpr, col = (is_a[q] ? t.n0 : t.k0) + 4 * (c - row * cpr);
         const bool ok = col + 4 <= (is_a[q] ? t.Npad : t.Kpad);          // the vector stays inside the readable row
         voff[q] = ok ? (unsigned)((row * (is_a[q] ? t.ldY : t.ldX) + col) * 4) : 0x7ffffff0u;
+        if (is_a[q] ? qa : qb) voff[q] = (unsigned)(((is_a[q] ? t.n0 : t.k0) * 32 + c * 4) * 4);
         loff[q] = (unsigned)(((is_a[q] ? 0 : kDwRows * a_ld) + 256 * (is_a[q] ? j : j - nA)) * 4);
     }
     const unsigned sa_step = kDwRows * ldY * 4, sb_step = kDwRows * ldX * 4;
@@ -860,17 +983,32 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
     const int n_base = t.n0 + 32 * gn, k_base = t.k0 + 32 * gk;
     const bool active = gn * 32 < a_ld && n_base < t.N && k_base < t.K;      // wave-uniform
     const int i = lane & 31, kk = lane >> 5;
-    const float* a_rd = smem + kk * a_ld + 32 * gn + i;
-    const float* b_rd = smem + kDwRows * a_ld + kk * b_ld + 32 * gk + i;
-    // one stage = 16 point-pairs: the operands are fetched from LDS into registers as a batch, so the ds_reads pipeline
+    // k-step (g, e) of a stage contracts points 8 g + 4 kk + e (lane half kk) - the assignment a Q4 piece has built in: a Q4 operand is
+    // ONE ds_read_b128 per group (its tile's piece (tile * 4 + g), this lane's 16 bytes), a row-major one four scalar reads of rows
+    // 8 g + 4 kk + e (rounds 1-4 walked rows 2 pp + kk: any order is right as long as both operands use the same)
+    const float* a_rd = qa ? smem + (gn * 4) * 256 + lane * 4 : smem + 4 * kk * a_ld + 32 * gn + i;
+    const float* b_rd = smem + kDwRows * a_ld + (qb ? (gk * 4) * 256 + lane * 4 : 4 * kk * b_ld + 32 * gk + i);
+    // one stage = 16 k-steps: the operands are fetched from LDS into registers as a batch, so the ds_reads pipeline
     // instead of each MFMA waiting on its own read
     auto compute = [&](int stage) {
         if (!active) return;
         const float* ar = a_rd + (stage % kDsStages) * stage_floats;
         const float* br = b_rd + (stage % kDsStages) * stage_floats;
         float av[16], bv[16];
+        if (qa) {
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) { av[pp] = ar[pp * 2 * a_ld]; bv[pp] = br[pp * 2 * b_ld]; }
+            for (int g = 0; g < 4; ++g) { const f32x4 v = *reinterpret_cast<const f32x4*>(ar + g * 256); av[4 * g] = v[0]; av[4 * g + 1] = v[1]; av[4 * g + 2] = v[2]; av[4 * g + 3] = v[3]; }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) av[pp] = ar[(8 * (pp >> 2) + (pp & 3)) * a_ld];
+        }
+        if (qb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const f32x4 v = *reinterpret_cast<const f32x4*>(br + g * 256); bv[4 * g] = v[0]; bv[4 * g + 1] = v[1]; bv[4 * g + 2] = v[2]; bv[4 * g + 3] = v[3]; }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) bv[pp] = br[(8 * (pp >> 2) + (pp & 3)) * b_ld];
+        }
 #pragma unroll
         for (int pp = 0; pp < 16; ++pp) acc[pp & 1] = CFN_MFMA(av[pp], bv[pp], acc[pp & 1]);   // two chains, summed at the end
     };
@@ -1178,7 +1316,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
 
     // ---- weight-gradient descriptors: they hold workspace pointers, so they are rebuilt (and uploaded, asynchronously,
     //      from host vectors that outlive the copy) only when the workspace binding moved - never on the steady path
-    if (B.bind_serial != q.bind_serial) {
+    if (B.bind_serial != q.bind_serial || B.q4 != q.q4) {      // (the tile descriptors carry operand pointers AND operand layouts)
         B.cur ^= 1;
         DwHost& Hs = B.host[B.cur];
         if (Hs.uploaded) BHIP(hipEventSynchronize(Hs.uploaded));     // the upload made from THIS set two rebuilds ago is long done
@@ -1197,6 +1335,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         BHIP(up(q.bias_maps, B.bias_maps.data(), B.bias_maps.size() * sizeof(BiasMap)));
         BHIP(hipEventRecord(Hs.uploaded, st));
         B.bind_serial = q.bind_serial;
+        B.q4 = q.q4;
     }
     const DwHost& Hc = B.host[B.cur];
 
@@ -1225,6 +1364,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
     // ---- 2. fused backward-data (+ bias partials and their reduction: every bias gradient is final here)
     BwdArgs ba{};                                              // (q.dbp needs no memset: every launched workgroup starts its row on its first tile)
     ba.wp = m->d_packed; ba.wp16 = m->d_packed16; ba.P = P; ba.n_wg = n_wg; ba.nb = B.nb;
+    ba.q4 = q.q4 ? 1 : 0;
     ba.g_theta = q.g_theta; ba.g_hr = q.g_hr; ba.g_ha = q.g_ha; ba.g_v = q.g_v; ba.g_feat = q.g_feat; ba.g_h = q.g_h;
     ba.mbits = reinterpret_cast<const uint32_t*>(q.mbits); ba.n_tiles = q.n_tiles; ba.S = q.S; ba.dbp = q.dbp;      // (points: ONE "ray" of S = P samples)
     ba.db_h = B.db_h; ba.db_feat = B.db_feat; ba.db_v = B.db_v; ba.db_ha = B.db_ha; ba.db_hr = B.db_hr; ba.db_theta = B.db_theta;

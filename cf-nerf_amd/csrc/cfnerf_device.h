@@ -486,9 +486,23 @@ __device__ __forceinline__ float relu_bit_apply(uint32_t bits, int e, float v) {
     return __int_as_float(__float_as_int(v) & m);
 }
 
+// ---- the Q4 layout of a wide stash stream ("fragment quads", round 5).  An MFMA output fragment gives lane l (column l & 31, half
+// h = l >> 5) registers r = 4 g + e: rows e + 8 g + 4 h of its column - four CONSECUTIVE ROWS per group g, i.e. four floats that are
+// 1 KB apart in a row-major [P, 256] array.  Row-major the stash therefore costs a dword store per element (or a round trip through
+// LDS, stash_rows); a timing build that wrote the same bytes as the fragments ARE - one buffer_store_dwordx4 per group, 64 lanes x 16 B
+// = one contiguous 1-KB piece per instruction, straight from the accumulator registers - measured -1.3 % on the train forward and
+// -3.5 % on backward-data (profiles/EXPERIMENTS.md).  So the wide streams of the train step (h, feature, v and their pre-activation
+// gradients) - in practice the trunk streams h[l], g_h[l] and g_feat, see fused_fwd_kernel - are laid out that way whenever the batch's tiles are whole (S a multiple of 64; fp32 mode):
+//   tile t = 64 consecutive points, half i = 32 points, n-tile nt = 32 columns, group g, lane, e:
+//   float offset  t * 64 C + ((i * C/32 + nt) * 4 + g) * 256 + lane * 4 + e    holds   A[64 t + 32 i + 8 g + 4 (lane >> 5) + e][32 nt + (lane & 31)]
+// A tile occupies the same 64 C floats as row-major, a 32-point half-tile is contiguous (one LDS stage of the weight-gradient
+// kernels), and those kernels consume a piece as it is: ONE ds_read_b128 per lane feeds four MFMA k-steps of a 32-column tile
+// (A and B use the same point assignment 8 g + 4 h + e, so the contraction order is consistent).
+__device__ __forceinline__ int q4_piece(int i, int nt, int g, int n_tiles) { return ((i * n_tiles + nt) * 4 + g) * 1024; }      // byte offset of a 1-KB piece inside its tile
+
 // epilogue of a layer: bias + activation -> LDS tile (and, in the train variants, the activation stash in HBM).
-// STASH is 0 (no stash code at all: the eval variants) or 1 (stash through a slab descriptor); store_tiles picks it
-// from gdst once per call, so the per-element work is max, ds_write (+ one buffer store, + two ops for the mask bit).
+// STASH is 0 (no stash code at all: the eval variants), 1 (row-major stash through a slab descriptor) or 2 (Q4: one dwordx4 per
+// group from the registers); store_tiles picks it once per call, so the per-element work is max, ds_write (+ a store, + two ops for the mask bit).
 template <int NTW, int ACT, int PREC, bool WANT_BITS, int STASH, bool BIAS_IN_ACC>
 __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                                  const float* __restrict__ wp, float* lds_dst, int ld, int col0,
@@ -496,7 +510,8 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                                                  uint32_t* __restrict__ mbits, const float* bias_pre) {
     const int lane = lane_id_opaque();
     const int rbase = 4 * (lane >> 5);
-    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, STASH ? rows_valid : 0, gld);      // unused (dead code) when STASH == 0
+    // (STASH == 2 without a stash - a train forward under no_grad: gdst is null, the descriptor is empty and the hardware drops the stores)
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, STASH == 1 ? rows_valid : (STASH == 2 && gdst != nullptr) ? kTileM : 0, gld);      // unused (dead code) when STASH == 0
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = nt0 + j * nts;
@@ -507,6 +522,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
         const int lcol = col0 + col;
         const int voff = (rbase * gld + col) * 4;
         uint32_t bits = 0;
+        [[maybe_unused]] u32x4 q4v;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -516,7 +532,14 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                 float v1 = BIAS_IN_ACC ? acc[i][j][r + 1] : acc[i][j][r + 1] + bv;
                 if (ACT == ACT_RELU) { v0 = relu_f(v0); v1 = relu_f(v1); }
                 act_store2<PREC>(lrow + rr * ld, lrow + (rr + 1) * ld, ld, lcol, v0, v1);
-                if (STASH) { slab_store(sink, voff, rr * gld * 4, v0); slab_store(sink, voff, (rr + 1) * gld * 4, v1); }
+                if (STASH == 1) { slab_store(sink, voff, rr * gld * 4, v0); slab_store(sink, voff, (rr + 1) * gld * 4, v1); }
+                if (STASH == 2) {                                     // Q4: the four rows of group g = r >> 2 leave as ONE 16-byte store
+                    if ((r & 3) == 0) { q4v[0] = __float_as_uint(v0); q4v[1] = __float_as_uint(v1); }
+                    else {
+                        q4v[2] = __float_as_uint(v0); q4v[3] = __float_as_uint(v1);
+                        __builtin_amdgcn_raw_buffer_store_b128(q4v, sink, lane * 16, __builtin_amdgcn_readfirstlane(q4_piece(i, nt, r >> 2, gld >> 5)), /*nt*/ 2);
+                    }
+                }
                 if (WANT_BITS) { bits = relu_bit_push(bits, v0); bits = relu_bit_push(bits, v1); }
             }
         // ReLU mask of this lane's fragment (32 rows of one column) as one word, in exactly the layout the
@@ -525,12 +548,17 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
     }
 }
 
-template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false, bool MAY_STASH = true, bool BIAS_IN_ACC = false>
+// MAY_STASH: the row-major element stores may be needed (a stream that is never copied out by stash_rows); Q4: the stream takes the Q4
+// layout (a compile-time property of the kernel variant: two epilogue flavours inside ONE kernel spilt 20-30 VGPRs of the train forward) -
+// gdst is then the TILE's base, the same address as its row-major slab.
+template <int NTW, int ACT, int PREC = PREC_F32, bool WANT_BITS = false, bool MAY_STASH = true, bool BIAS_IN_ACC = false, bool Q4 = false>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts,
                                             const float* __restrict__ wp, float* lds_dst, int ld, int col0,
                                             float* __restrict__ gdst, int gld, int rows_valid,
                                             uint32_t* __restrict__ mbits = nullptr, const float* bias_pre = nullptr) {
-    if (MAY_STASH && gdst != nullptr)
+    if (Q4)
+        store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 2, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
+    else if (MAY_STASH && gdst != nullptr)
         store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 1, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);
     else
         store_tiles_impl<NTW, ACT, PREC, WANT_BITS, 0, BIAS_IN_ACC>(acc, s, nt0, nts, wp, lds_dst, ld, col0, gdst, gld, rows_valid, mbits, bias_pre);

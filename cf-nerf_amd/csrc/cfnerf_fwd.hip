@@ -88,9 +88,13 @@ __device__ __forceinline__ void encode_tile(float* act, const float* rowinfo, co
 struct FwdKargs { FwdArgs A; NetTab T; };
 static_assert(offsetof(FwdKargs, T) == (sizeof(FwdArgs) + alignof(NetTab) - 1) / alignof(NetTab) * alignof(NetTab), "kernarg layout");
 
-template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC>
+// Q4 (train, fp32, whole tiles only - launch_fused_fwd picks the variant from FwdArgs::q4): the trunk activations h[0 .. D-1], 8 of the 9.5
+// W-wide units the forward stashes per point, leave as Q4 pieces straight from the accumulator registers (cfnerf_device.h) instead of by
+// rows out of LDS.
+template <int W, int MODE /*0 rays, 1 points*/, bool TRAIN, int PREC, bool Q4 = false>
 __global__ __launch_bounds__(FwdCfg<W>::NTHR, 2)
 void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
+    static_assert(!Q4 || (TRAIN && PREC == PREC_F32), "the Q4 stash layout exists for the fp32 train variants only");
     // The arguments live in the kernarg segment, so every per-layer descriptor read is a scalar load from constant
     // memory.  (Through a global pointer the compiler must assume the kernel's own stores may alias the table and issues
     // VECTOR loads with a full wait in front of each layer's first operand fetch: two or three dependent L2 round trips.)
@@ -301,8 +305,8 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 __syncthreads();
                 float* st = (te_st0 != nullptr) ? te_st0 + (size_t)l * te_st_step : nullptr;
                 uint32_t* mb = (te_mb0 != nullptr) ? te_mb0 + (size_t)l * te_mb_step : nullptr;
-                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;      // stash by rows out of LDS (see stash_rows)
-                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds && !Q4;      // stash by rows out of LDS (see stash_rows) ...
+                store_tiles<C::NTW, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true, Q4>(acc, tl_cur, wave, kWv, wp, act, LD, 0, st, W, rows_valid, mb);      // ... or (Q4) as pieces from the registers
                 __syncthreads();
                 if (kRows && st != nullptr) stash_rows<W, kThr>(act, LD, st, rows_valid);
                 tl_cur = tl_nxt; tl_nxt = tl_nn;
@@ -368,6 +372,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     }
                 }
                 __syncthreads();
+                // (feature and v stay row-major in every variant: with accF AND accA live, the Q4 stores of this epilogue spilt 13 VGPRs)
                 constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
                 store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, tl_ft, wave, kWv, wp, act, LD, 0,
                                               st_feat ? st_feat + p0 * W : nullptr, W, rows_valid);
@@ -1077,9 +1082,9 @@ static int max_blocks_per_cu(const void* fn, size_t lds, int threads) {
     return nb;
 }
 
-template <int W, int MODE, bool TRAIN, int PREC>
+template <int W, int MODE, bool TRAIN, int PREC, bool Q4 = false>
 static hipError_t launch_fwd_t(const FwdArgs& a, const NetTab& ht, int n_cu, int per_cu, hipStream_t st, int* grid_out) {
-    auto fn = fused_fwd_kernel<W, MODE, TRAIN, PREC>;
+    auto fn = fused_fwd_kernel<W, MODE, TRAIN, PREC, Q4>;
     const size_t lds = fwd_lds_bytes(W, ht.ha_sz, a.K);
     const int64_t units = (MODE == 0) ? a.N : (a.P + kTileM - 1) / kTileM;
     int grid = (int)std::min<int64_t>(units, (int64_t)n_cu * per_cu);
@@ -1095,6 +1100,8 @@ static hipError_t launch_fwd_w(const FwdArgs& a, const NetTab& ht, int mode, boo
         if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out);
         return train ? launch_fwd_t<W, 1, true, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_BF16X3>(a, ht, n_cu, per_cu, st, grid_out);
     }
+    if (train && a.q4)            // whole tiles + a stash in fp32 mode: the variant that writes the wide streams as Q4 pieces
+        return mode == 0 ? launch_fwd_t<W, 0, true, PREC_F32, true>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 1, true, PREC_F32, true>(a, ht, n_cu, per_cu, st, grid_out);
     if (mode == 0) return train ? launch_fwd_t<W, 0, true, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 0, false, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out);
     return train ? launch_fwd_t<W, 1, true, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out) : launch_fwd_t<W, 1, false, PREC_F32>(a, ht, n_cu, per_cu, st, grid_out);
 }
@@ -1113,7 +1120,8 @@ hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& ht, int mode, bool t
 template <int W>
 static hipError_t fwd_attrs_w(int ha, int* per_cu_out) {
     const size_t lds = fwd_lds_bytes(W, ha, kMaxK);      // the limit; a launch asks for what its K needs
-    const void* fns[8] = {
+    const void* fns[10] = {
+        reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_F32, true>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, true, PREC_F32, true>),
         reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_F32>),
         reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, false, PREC_F32>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 1, true, PREC_F32>),
         reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, false, PREC_BF16X3>), reinterpret_cast<const void*>(fused_fwd_kernel<W, 0, true, PREC_BF16X3>),

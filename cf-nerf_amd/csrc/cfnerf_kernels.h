@@ -49,6 +49,7 @@ struct FwdArgs {
     float *st_at;                        // [tiles,K,64,2] e = exp(-sigma dist) = 1 - alpha, transmittance T of the composite
     uint32_t* st_mbits;                  // [D+1][tiles][W/32][64] ReLU masks as fragment-ordered bit words
     int64_t n_tiles;                     // tiles of the launch (rays * chunks per ray)
+    int32_t q4;                          // 1: the trunk activations h take the Q4 layout (cfnerf_device.h: whole tiles, fp32 mode; picks the kernel variant)
 };
 
 hipError_t launch_fused_fwd(const FwdArgs& a, const NetTab& host_tab, int mode, bool train, int prec, int n_cu, int per_cu, hipStream_t st, int* grid_out);

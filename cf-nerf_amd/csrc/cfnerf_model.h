@@ -76,6 +76,7 @@ struct Stash {
     int64_t N = 0; int S = 0, K = 0, flags = 0;
     bool valid = false;             // a STASH forward has filled it
     bool points = false;            // ... in points mode (cfnerf_network_fwd: N = 1, S = P): differentiated by cfnerf_network_bwd
+    bool q4 = false;                // ... with the trunk streams (h; then g_h, g_feat) in the Q4 layout (cfnerf_device.h): whole tiles, fp32
     uint64_t generation = 0;        // bumped by every STASH forward; cfnerf_render_bwd checks the caller's copy against it
 
     // binding

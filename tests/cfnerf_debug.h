@@ -27,6 +27,9 @@ CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int
 /* copy a buffer of the last STASH forward / its backward ("h", "g_h", "feat", "v", "theta", "enc", "at", ...) into dst (device);
  * returns the float count, -count if max_floats is too small, -1 if there is no such buffer */
 CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, int layer, float* dst, int64_t max_floats, cfnerf_stream s);
+/* 1 if the last STASH forward wrote its trunk streams ("h", and its backward "g_h", "g_feat") in the Q4 layout (csrc/cfnerf_device.h:
+ * whole 64-point tiles, fp32 mode), 0 if row-major, -1 without a stash; tests/util_hip.py::q4_to_rows undoes the layout */
+CFNERF_API int cfnerf_debug_stash_q4(cfnerf_model* m);
 /* the weight-gradient tiles of a configuration at P points: 12 int32 per tile + 4 destination segments each */
 CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles);
 /* the blocks of that plan for a point count and CU count: 5 int64 per block {kind, tile, split, pb, pe}, per tile its split count,

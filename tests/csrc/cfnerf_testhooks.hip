@@ -66,6 +66,7 @@ CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, in
     if (hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) return -1;
     return cnt;
 }
+CFNERF_API int cfnerf_debug_stash_q4(cfnerf_model* m) { return (!m || !m->stash.valid) ? -1 : (m->stash.q4 ? 1 : 0); }
 // operand table entry by name: out[4] = {w_off, b_off, kc, nt}
 CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int index, uint32_t* out) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;

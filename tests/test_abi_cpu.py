@@ -48,7 +48,7 @@ def test_dynamic_symbol_table_is_exactly_the_header():
     exported = _dynamic_symbols(L.LIB_PATH)
     abi = _declared(os.path.join(ROOT, "include", "cfnerf.h"))
     declared_hooks = _declared(os.path.join(ROOT, "tests", "cfnerf_debug.h"))
-    assert len(abi) == 33 and len(declared_hooks) == 6 and not (abi & declared_hooks)
+    assert len(abi) == 33 and len(declared_hooks) == 7 and not (abi & declared_hooks)
     assert all(h.startswith("cfnerf_debug_") for h in declared_hooks), declared_hooks
     assert exported == abi, {"undeclared": sorted(exported - abi)[:10], "missing": sorted(abi - exported)}
     assert not any("debug" in e for e in exported)

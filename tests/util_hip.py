@@ -76,8 +76,19 @@ def fern_rays(rng, n, H=378, W=504, focal=407.5658):
 G_TIGHT = 2e-4            # of the tensor's largest entry
 
 
+def q4_to_rows(flat, cols):
+    """A wide stash stream in the Q4 layout (csrc/cfnerf_device.h: per 64-point tile [half i][n-tile][group g][lane = 32 h + c][e], element =
+    A[64 t + 32 i + 8 g + 4 h + e][32 nt + c]) as the row-major [P, cols] matrix; `flat` is a device or host tensor of P * cols floats."""
+    nt = cols // 32
+    return flat.reshape(-1, 2, nt, 4, 2, 32, 4).permute(0, 1, 3, 4, 6, 2, 5).reshape(-1, cols)
+
+
+Q4_STREAMS = ("h", "g_h", "g_feat")
+
+
 def stash_copy(net, name, layer, n, keep=None):
-    """buffer `name` of the last STASH forward as a CPU tensor; keep = (lo, hi): only that range of its floats crosses to the host"""
+    """buffer `name` of the last STASH forward as a CPU tensor in ROW-MAJOR order (the Q4 streams of a whole-tile fp32 forward are
+    un-permuted here); keep = (lo, hi): only that range of its floats crosses to the host"""
     import ctypes as C
     import hooks
     from cfnerf_amd import _lib as L
@@ -87,6 +98,10 @@ def stash_copy(net, name, layer, n, keep=None):
     out = torch.empty(n, device="cuda")
     r = fn(net.handle, name.encode(), layer, C.c_void_p(out.data_ptr()), n, L.stream())
     assert r == n, (name, layer, r, n)
+    q4 = hooks.lib().cfnerf_debug_stash_q4
+    q4.restype, q4.argtypes = C.c_int, [C.c_void_p]
+    if name in Q4_STREAMS and q4(net.handle) == 1:
+        out = q4_to_rows(out, net.W).reshape(-1)
     return (out if keep is None else out[keep[0]:keep[1]]).cpu()
 
 
