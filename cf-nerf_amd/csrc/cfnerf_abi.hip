@@ -379,6 +379,10 @@ int cfnerf_model_set_precision(cfnerf_model* m, int mode) {
     if (!m) return fail(CFNERF_E_INVALID, "model is NULL");
     if (mode != 0 && mode != 1) return fail(CFNERF_E_INVALID, "precision mode must be 0 (fp32 MFMA) or 1 (bf16x3 split MFMA)");
     const bool need_pack16 = mode != 0 && m->precision == 0 && m->flat != nullptr;
+    if (mode != m->precision && m->stash.valid) {      // a stashed forward belongs to the mode it ran in (operand copies, the layout of its wide streams): its
+        m->stash.valid = false;                         // backward in the other mode would read it wrongly - dropped like a re-bound workspace
+        ++m->stash.generation;
+    }
     m->precision = mode;
     if (need_pack16) {      // bring the bf16 copy up to date with the current parameters (rare call: fully synchronous)
         HIPCHK(hipDeviceSynchronize());

@@ -853,37 +853,47 @@ __device__ __attribute__((noinline)) void dw_big_body_q4(const DwTile* __restric
     const float* b_rd = smem + (kOpBytes / 4) + (jk * 4) * 256 + lane * 4;
     issue(0); dma_stage = 1;
     int buf = 0;
+    if (!active) {               // a wave without an output tile (partial 256 x 256 tiles) only moves its share of the pieces and keeps step with the barriers
+        for (int p = 0; p < rows_u; p += kDwRows) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (p + kDwRows < rows_u) issue(buf ^ 1);
+            ++dma_stage;
+            buf ^= 1;
+        }
+        return;
+    }
+    // (the MFMA loop is NOT wrapped in `if (active)`: with the accumulators updated on one side of a branch only, the compiler copied all of
+    //  them at every stage - 32 to 64 v_mov_b64 per iteration - and, at 2 x 4, spilt 48 of them inside the loop)
     for (int p = 0; p < rows_u; p += kDwRows) {
         const bool more = p + kDwRows < rows_u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the current stage have landed
         __syncthreads();                                         // ... everyone's have, and everyone is done reading the other buffer
-        if (more && !active) issue(buf ^ 1);
-        if (active) {
-            const float* ar = a_rd + buf * (kDwRows * 256);
-            const float* br = b_rd + buf * (kDwRows * 256);
+        const float* ar = a_rd + buf * (kDwRows * 256);
+        const float* br = b_rd + buf * (kDwRows * 256);
+        // step = (group g, half): 8-byte operand reads - a lane's points 8 g + 4 h + 2 half + {0, 1} of its column - for 16 MFMAs
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 av[4], bv[2];
+        for (int st = 0; st < 8; ++st) {
+            f32x2 av[4], bv[2];
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) av[tn] = *reinterpret_cast<const f32x4*>(ar + (tn * 4 + g) * 256);
-                bv[0] = *reinterpret_cast<const f32x4*>(br + g * 256);
-                if (!arr1) bv[1] = *reinterpret_cast<const f32x4*>(br + (4 + g) * 256);
+            for (int tn = 0; tn < 4; ++tn) av[tn] = *reinterpret_cast<const f32x2*>(ar + (tn * 4 + (st >> 1)) * 256 + 2 * (st & 1));
+            bv[0] = *reinterpret_cast<const f32x2*>(br + (st >> 1) * 256 + 2 * (st & 1));
+            if (!arr1) bv[1] = *reinterpret_cast<const f32x2*>(br + (4 + (st >> 1)) * 256 + 2 * (st & 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) {
-                        acc[tn][0] = CFN_MFMA(av[tn][e], bv[0][e], acc[tn][0]);
-                        if (!arr1) acc[tn][1] = CFN_MFMA(av[tn][e], bv[1][e], acc[tn][1]);
-                    }
-                    // the next stage's pieces go out one at a time between the first MFMA groups (a burst in front of them keeps both waves of a SIMD off the matrix pipe)
-                    if (more && g < 2) issue_h(buf ^ 1, (g * 4 + e) >> 1, (g * 4 + e) & 1);
+                for (int tn = 0; tn < 4; ++tn) {
+                    acc[tn][0] = CFN_MFMA(av[tn][e], bv[0][e], acc[tn][0]);
+                    if (!arr1) acc[tn][1] = CFN_MFMA(av[tn][e], bv[1][e], acc[tn][1]);
                 }
+                // the next stage's pieces go out one at a time between the first MFMA groups (a burst in front of them keeps both waves of a SIMD off the matrix pipe)
+                if (more && st < 4) issue_h(buf ^ 1, (st * 2 + e) >> 1, (st * 2 + e) & 1);
             }
         }
         ++dma_stage;
         buf ^= 1;
     }
-    if (active) {
+    {
         gf_ptr out = (gf_ptr)(partials + (size_t)blk.split * n_params);
         const int kcol = t.k0 + 32 * jk + (lane & 31);
         gf_ptr o = out + ((size_t)t.seg_dst[0] + t.dst_col + kcol);

@@ -248,7 +248,8 @@ CFNERF_API int cfnerf_adam_step(cfnerf_model* m, float* flat_params, const float
  * (v_mfma_f32_32x32x2_f32).  1: "bf16x3" - every fp32 operand is carried as hi + lo bf16 and a product is evaluated
  * as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo*lo term is ~2^-18
  * relative); it is held to the SAME parity tolerances by tests/test_hip_bf16x3.py.  Applies to the fused forward,
- * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).                */
+ * the backward-data kernel and the large weight-gradient GEMMs (the narrow ones stay exact fp32).  A stashed forward belongs to
+ * the mode it ran in: CHANGING the mode drops it (its generation id is retired, like after cfnerf_model_set_workspace).     */
 CFNERF_API int cfnerf_model_set_precision(cfnerf_model* m, int mode);
 
 /* Arithmetic of the flow phase of the fused kernels (the K conditional Sylvester flows, MOD:401-413 / FLW:225-268, the activations
