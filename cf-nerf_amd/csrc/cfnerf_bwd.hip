@@ -346,7 +346,7 @@ __device__ __forceinline__ void store_bwd_impl(const f32x16 (&acc)[2][NTW], cons
                     q4v[0] = __float_as_uint(v0); q4v[1] = __float_as_uint(v1);
                 } else {
                     q4v[2] = __float_as_uint(v0); q4v[3] = __float_as_uint(v1);
-                    __builtin_amdgcn_raw_buffer_store_b128(q4v, sink, lane * 16, __builtin_amdgcn_readfirstlane(q4_piece(i, nt, r >> 2, gld >> 5)), /*nt*/ 2);
+                    q4_store(q4v, sink, lane, q4_piece(i, nt, r >> 2, gld >> 5));
                 }
                 csum += v0; csum += v1;
             }

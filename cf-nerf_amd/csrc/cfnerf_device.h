@@ -499,6 +499,15 @@ __device__ __forceinline__ float relu_bit_apply(uint32_t bits, int e, float v) {
 // kernels), and those kernels consume a piece as it is: ONE ds_read_b128 per lane feeds four MFMA k-steps of a 32-column tile
 // (A and B use the same point assignment 8 g + 4 h + e, so the contraction order is consistent).
 __device__ __forceinline__ int q4_piece(int i, int nt, int g, int n_tiles) { return ((i * n_tiles + nt) * 4 + g) * 1024; }      // byte offset of a 1-KB piece inside its tile
+// One lane's 16 bytes of a piece.  The piece offset rides in the VECTOR offset, soffset is the literal 0 - on purpose: with the offset in
+// an SGPR (the form every other stream uses) a 16-byte buffer store reads its data registers LATE on gfx950, and the epilogue's next
+// v_and / v_max into the same four VGPRs - a few instructions on - reached memory instead: sparse, run-to-run different garbage in g_h
+// under two workgroups per CU (round 5, tests/tools/determinism_diag.py: lanes 12-15 of every row of 16, first dword, values of the NEXT
+// group).  LLVM's hazard recognizer knows the ">64-bit store, then VALU write of its data" hazard only for the form WITHOUT an SGPR offset
+// (GCNHazardRecognizer::createsVALUHazard) and inserts the wait state there; with the literal 0 the same code is bit-reproducible.
+__device__ __forceinline__ void q4_store(u32x4 v, __amdgpu_buffer_rsrc_t sink, int lane, int piece_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, sink, lane * 16 + piece_bytes, 0, /*nt*/ 2);
+}
 
 // epilogue of a layer: bias + activation -> LDS tile (and, in the train variants, the activation stash in HBM).
 // STASH is 0 (no stash code at all: the eval variants), 1 (row-major stash through a slab descriptor) or 2 (Q4: one dwordx4 per
@@ -537,7 +546,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
                     if ((r & 3) == 0) { q4v[0] = __float_as_uint(v0); q4v[1] = __float_as_uint(v1); }
                     else {
                         q4v[2] = __float_as_uint(v0); q4v[3] = __float_as_uint(v1);
-                        __builtin_amdgcn_raw_buffer_store_b128(q4v, sink, lane * 16, __builtin_amdgcn_readfirstlane(q4_piece(i, nt, r >> 2, gld >> 5)), /*nt*/ 2);
+                        q4_store(q4v, sink, lane, q4_piece(i, nt, r >> 2, gld >> 5));
                     }
                 }
                 if (WANT_BITS) { bits = relu_bit_push(bits, v0); bits = relu_bit_push(bits, v1); }
