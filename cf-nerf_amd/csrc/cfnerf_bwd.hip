@@ -871,23 +871,24 @@ __device__ __attribute__((noinline)) void dw_big_body_q4(const DwTile* __restric
         __syncthreads();                                         // ... everyone's have, and everyone is done reading the other buffer
         const float* ar = a_rd + buf * (kDwRows * 256);
         const float* br = b_rd + buf * (kDwRows * 256);
-        // step = (group g, half): 8-byte operand reads - a lane's points 8 g + 4 h + 2 half + {0, 1} of its column - for 16 MFMAs
+        // per group g (8 points): one conflict-free ds_read_b128 per 32-column tile and lane - four k-steps of that tile - then 32 MFMAs
+        // (8-byte reads would keep fewer operand registers live but run at half the LDS rate: lanes l and l + 16 share banks)
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            f32x2 av[4], bv[2];
+        for (int g = 0; g < 4; ++g) {
+            f32x4 av[4], bv[2];
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) av[tn] = *reinterpret_cast<const f32x2*>(ar + (tn * 4 + (st >> 1)) * 256 + 2 * (st & 1));
-            bv[0] = *reinterpret_cast<const f32x2*>(br + (st >> 1) * 256 + 2 * (st & 1));
-            if (!arr1) bv[1] = *reinterpret_cast<const f32x2*>(br + (4 + (st >> 1)) * 256 + 2 * (st & 1));
+            for (int tn = 0; tn < 4; ++tn) av[tn] = *reinterpret_cast<const f32x4*>(ar + (tn * 4 + g) * 256);
+            bv[0] = *reinterpret_cast<const f32x4*>(br + g * 256);
+            if (!arr1) bv[1] = *reinterpret_cast<const f32x4*>(br + (4 + g) * 256);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
                     acc[tn][0] = CFN_MFMA(av[tn][e], bv[0][e], acc[tn][0]);
                     if (!arr1) acc[tn][1] = CFN_MFMA(av[tn][e], bv[1][e], acc[tn][1]);
                 }
                 // the next stage's pieces go out one at a time between the first MFMA groups (a burst in front of them keeps both waves of a SIMD off the matrix pipe)
-                if (more && st < 4) issue_h(buf ^ 1, (st * 2 + e) >> 1, (st * 2 + e) & 1);
+                if (more && g < 2) issue_h(buf ^ 1, (g * 4 + e) >> 1, (g * 4 + e) & 1);
             }
         }
         ++dma_stage;
