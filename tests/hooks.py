@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "cf-nerf_amd", "build", "libcfnerf_testhooks.so")
+# CFNERF_TESTHOOKS_LIB: another build of the hooks (tools/asan_host.sh runs the host planners under the sanitizers through it)
+PATH = os.environ.get("CFNERF_TESTHOOKS_LIB") or os.path.join(ROOT, "cf-nerf_amd", "build", "libcfnerf_testhooks.so")
 _lib = None
 
 

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r04"
+TAG = "r05"
 
 
 def line(name):
@@ -46,8 +46,8 @@ def test_bench_lines_carry_the_contract(name, workload):
         assert p["vs_reference_run"]["agree"] is True and p["vs_reference_run"]["max_abs_held_out_psnr_diff_db"]["120"] <= 0.01
 
 
-@pytest.mark.parametrize("bench,stats,kernel", [("c2", "train", "fused_fwd_kernel<256, 0, true, 0>"), ("eval", "eval", "fused_fwd_kernel<256, 0, false, 0>"),
-                                                ("w512", "w512_train", "fused_fwd_kernel<512, 0, true, 0>")])
+@pytest.mark.parametrize("bench,stats,kernel", [("c2", "train", "fused_fwd_kernel<256, 0, true, 0, true>"), ("eval", "eval", "fused_fwd_kernel<256, 0, false, 0, false>"),
+                                                ("w512", "w512_train", "fused_fwd_kernel<512, 0, true, 0, true>")])
 def test_rocprof_average_agrees_with_the_bench_line(bench, stats, kernel):
     d = line(bench)
     with open(os.path.join(P, f"{TAG}_{stats}_kernel_stats.csv")) as f:

@@ -16,9 +16,11 @@ for f in cfnerf_fwd cfnerf_bwd cfnerf_tail cfnerf_abi; do
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$R/cf-nerf_amd/csrc/cfnerf_exports.map" -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -o "$R/cf-nerf_amd/libvar_asan.so" "$O"/cfnerf_fwd.o "$O"/cfnerf_bwd.o "$O"/cfnerf_tail.o "$O"/cfnerf_abi.o
+# the host planners (operand packing, weight-gradient plan) are header-only code the tests reach through the test-hooks library: same flags
+hipcc $F "-DCFN_FOR_EACH_WIDTH(X)=X(256)" -I"$R/cf-nerf_amd/csrc" -I"$R/include" -shared -shared-libsan "$R/tests/csrc/cfnerf_testhooks.hip" -o "$O/libcfnerf_testhooks_asan.so"
 cd "$R"
 LOG="$O/asan_run.log"
-CFNERF_LIB="$R/cf-nerf_amd/libvar_asan.so" LD_LIBRARY_PATH="$RT:${LD_LIBRARY_PATH:-}" LD_PRELOAD="$RT/libclang_rt.asan-x86_64.so" \
+CFNERF_TESTHOOKS_LIB="$O/libcfnerf_testhooks_asan.so" CFNERF_LIB="$R/cf-nerf_amd/libvar_asan.so" LD_LIBRARY_PATH="$RT:${LD_LIBRARY_PATH:-}" LD_PRELOAD="$RT/libclang_rt.asan-x86_64.so" \
   ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 \
   python -m pytest tests/test_abi_cpu.py -q -p no:cacheprovider -s 2>&1 | tee "$LOG" | tail -3
 if grep -q "runtime error\|AddressSanitizer" "$LOG"; then echo "SANITIZER REPORTS:"; grep -n "runtime error\|AddressSanitizer" "$LOG" | head; exit 1; fi

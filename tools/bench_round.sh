@@ -1,8 +1,8 @@
 #!/bin/bash
-# the bench lines of one round, one file per config (run on the GPU box through gpurun):  tools/bench_round.sh r04
+# the bench lines of one round, one file per config (run on the GPU box through gpurun):  tools/bench_round.sh r05
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run this through gpurun}"
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; T="${1:-r04}"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; T="${1:-r05}"; mkdir -p "$O"
 cd "$R"
 python bench.py > "$O/bench_${T}_default.json" 2> "$O/bench_${T}_default.err"
 B="--no-cpu-baseline --no-alt"

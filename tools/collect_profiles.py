@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(ROOT, "profiles")
 
 for n, out in (("train", "train"), ("eval", "eval"), ("train_b16", "train_bf16x3"), ("w512", "w512_train"), ("c4", "c4_train"), ("c3", "c3_train"), ("k64", "k64_train")):
@@ -54,8 +54,8 @@ traffic = {}
 note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/%s_pmc_summary.txt, recipe tools/profile_round.sh); FETCH_SIZE "
         "doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); WRITE_SIZE uncorrected; mfma_busy_frac = "
         "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)" % tag)
-for key, suffix, kern in (("C2:train", "", "fused_fwd_kernel<256, 0, true, 0>"), ("C2:eval", "_eval", "fused_fwd_kernel<256, 0, false, 0>"),
-                          ("W512:train", "_w512", "fused_fwd_kernel<512, 0, true, 0>")):
+for key, suffix, kern in (("C2:train", "", "fused_fwd_kernel<256, 0, true, 0, true>"), ("C2:eval", "_eval", "fused_fwd_kernel<256, 0, false, 0, false>"),
+                          ("W512:train", "_w512", "fused_fwd_kernel<512, 0, true, 0, true>")):      # (train: the Q4 variant, round 5)
     f, w, m = pmc("pmc_fetch" + suffix), pmc("pmc_write" + suffix), pmc("pmc_mfma" + suffix)
     if kern in f and kern in w:
         e = {"kernel": kern, "FETCH_SIZE_KB": f[kern]["FETCH_SIZE"], "WRITE_SIZE_KB": w[kern]["WRITE_SIZE"],
