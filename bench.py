@@ -673,7 +673,7 @@ def main():
                                    "(hi/lo split of every epilogue element, mask bits, flows) = 23 % - the bf16 MFMA does not co-issue with them "
                                    "either - and 38 % stalls at the 2.07 GHz this kernel clocks; costed in round 3: a free activation stash "
                                    "would give 0.40, the remaining candidates sum to 0.42-0.45 (profiles/r03_pmc_summary.txt section pmc_b16, "
-                                   "DESIGN.md section 3 'Measured and rejected', round 3)"}
+                                   "profiles/EXPERIMENTS.md, round 3)"}
 
     # BASELINE config 4 (K = 16, 1024 rays per GPU) next to the line when the job spans several GPUs (default run only)
     cfg4 = None
