@@ -603,6 +603,29 @@ template <bool FAST> struct Num {
     }
 };
 
+// Num<true> on TWO latent samples per lane (the flow phase from 16 latents on, cfnerf_fwd.hip): the multiplies and adds around the hardware
+// transcendentals become packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per issue slot), the
+// transcendentals themselves stay one per component.  Component for component the SAME operations as Num<true>: bit-identical values.
+struct Num2 {
+    static __device__ __forceinline__ f32x2 exp2(f32x2 x) { f32x2 r; r[0] = __builtin_amdgcn_exp2f(x[0]); r[1] = __builtin_amdgcn_exp2f(x[1]); return r; }
+    static __device__ __forceinline__ f32x2 log2(f32x2 x) { f32x2 r; r[0] = __builtin_amdgcn_logf(x[0]); r[1] = __builtin_amdgcn_logf(x[1]); return r; }
+    static __device__ __forceinline__ f32x2 rcp(f32x2 x) { f32x2 r; r[0] = __builtin_amdgcn_rcpf(x[0]); r[1] = __builtin_amdgcn_rcpf(x[1]); return r; }
+    static __device__ __forceinline__ f32x2 abs(f32x2 x) { f32x2 r; r[0] = fabsf(x[0]); r[1] = fabsf(x[1]); return r; }
+    static __device__ __forceinline__ f32x2 exp(f32x2 x) { return exp2(x * 1.4426950408889634f); }
+    static __device__ __forceinline__ f32x2 ln(f32x2 x) { return log2(x) * 0.6931471805599453f; }
+    static __device__ __forceinline__ f32x2 tanh(f32x2 x) {
+        const f32x2 r = rcp(1.f + exp2(x * 2.8853900817779268f));
+        f32x2 o; o[0] = __builtin_fmaf(-2.f, r[0], 1.f); o[1] = __builtin_fmaf(-2.f, r[1], 1.f);
+        return o;
+    }
+    static __device__ __forceinline__ f32x2 sigmoid(f32x2 x) { return rcp(1.f + exp2(x * -1.4426950408889634f)); }
+    static __device__ __forceinline__ f32x2 softplus(f32x2 x) {
+        const f32x2 s = log2(1.f + exp2(x * 1.4426950408889634f)) * 0.6931471805599453f;
+        f32x2 o; o[0] = x[0] > 20.f ? x[0] : s[0]; o[1] = x[1] > 20.f ? x[1] : s[1];
+        return o;
+    }
+};
+
 // Transcendentals of the BACKWARD recompute.  The forward evaluates the flows with correctly rounded libm calls (parity
 // of the rendered values); the backward recomputes the same quantities on the hardware exp / reciprocal (~1 ulp each): tanh =
 // 1 - 2 / (1 + e^2x) (saturates correctly at both ends), sigmoid = 1 / (1 + e^-x).  ~8 instead of ~30 instructions per tanh,
@@ -745,6 +768,49 @@ __device__ __forceinline__ void flows_fwd(const float (&th)[84], float (&z)[3], 
             ld_a += M::ln(fabsf((1.f - ta * ta) * (th[72 + f] * th[76 + f]) + 1.f) + 1e-08f);
         }
     }
+}
+
+// (p[h], p[h]) for a constant h: folds into the op_sel bits of the packed instruction that reads it
+__device__ __forceinline__ f32x2 pair_half(const f32x2 p, const int h) { const float v = h ? p[1] : p[0]; f32x2 r; r[0] = v; r[1] = v; return r; }
+// the same flows for TWO latent samples of a point (components of the f32x2 values), on Num2: operation for operation flows_fwd<LOGDET, true>.
+// The flow parameters come as the 42 register PAIRS tp[j] = (th[2 j], th[2 j + 1]): a packed instruction takes either half of a pair for both
+// of its components (op_sel), so th[j] * (z_a, z_b) needs no broadcast copy - a per-element splat into a pair of its own cost 84 more registers.
+template <bool LOGDET>
+__device__ __forceinline__ void flows_fwd2(const f32x2 (&tp)[42], f32x2 (&z)[3], f32x2& a, f32x2& ld_rgb, f32x2& ld_a) {
+    using M = Num2;
+#define CFN_TH(j) pair_half(tp[(j) >> 1], (j) & 1)
+    ld_rgb = 0.f; ld_a = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const bool odd = f & 1;
+        const f32x2 zp0 = odd ? z[2] : z[0], zp1 = z[1], zp2 = odd ? z[0] : z[2];
+        const f32x2 d2_0 = CFN_TH(48 + 0 + f), d2_1 = CFN_TH(48 + 4 + f), d2_2 = CFN_TH(48 + 8 + f);
+        const f32x2 d1_0 = CFN_TH(36 + 0 + f), d1_1 = CFN_TH(36 + 4 + f), d1_2 = CFN_TH(36 + 8 + f);
+        const f32x2 pre0 = ((d2_0 * zp0 + CFN_TH((1 * 3 + 0) * 4 + f) * zp1) + CFN_TH((2 * 3 + 0) * 4 + f) * zp2) + CFN_TH(60 + 0 + f);
+        const f32x2 pre1 = (d2_1 * zp1 + CFN_TH((2 * 3 + 1) * 4 + f) * zp2) + CFN_TH(60 + 4 + f);
+        const f32x2 pre2 = d2_2 * zp2 + CFN_TH(60 + 8 + f);
+        const f32x2 t0 = M::tanh(pre0), t1 = M::tanh(pre1), t2 = M::tanh(pre2);
+        const f32x2 u0 = (d1_0 * t0 + CFN_TH((0 * 3 + 1) * 4 + f) * t1) + CFN_TH((0 * 3 + 2) * 4 + f) * t2;
+        const f32x2 u1 = d1_1 * t1 + CFN_TH((1 * 3 + 2) * 4 + f) * t2;
+        const f32x2 u2 = d1_2 * t2;
+        z[0] = (odd ? u2 : u0) + z[0];
+        z[1] = u1 + z[1];
+        z[2] = (odd ? u0 : u2) + z[2];
+        const f32x2 ta = M::tanh(CFN_TH(76 + f) * a + CFN_TH(80 + f));
+        a = CFN_TH(72 + f) * ta + a;
+        if (LOGDET) {
+            // d1 d2 of flows (f, f ^ 1) as ONE packed product of two parameter pairs; its half f & 1 serves both latents
+            const f32x2 dd0 = tp[(36 + 0 + f) >> 1] * tp[(48 + 0 + f) >> 1], dd1 = tp[(36 + 4 + f) >> 1] * tp[(48 + 4 + f) >> 1];
+            const f32x2 dd2 = tp[(36 + 8 + f) >> 1] * tp[(48 + 8 + f) >> 1], dda = tp[(72 + f) >> 1] * tp[(76 + f) >> 1];
+#define CFN_HALF(v) pair_half(v, f & 1)
+            ld_rgb += (M::ln(M::abs((1.f - t0 * t0) * CFN_HALF(dd0) + 1.f) + 1e-08f) +
+                       M::ln(M::abs((1.f - t1 * t1) * CFN_HALF(dd1) + 1.f) + 1e-08f)) +
+                      M::ln(M::abs((1.f - t2 * t2) * CFN_HALF(dd2) + 1.f) + 1e-08f);
+            ld_a += M::ln(M::abs((1.f - ta * ta) * CFN_HALF(dda) + 1.f) + 1e-08f);
+#undef CFN_HALF
+        }
+    }
+#undef CFN_TH
 }
 
 // ---- LDS-DMA helpers (the fp32 big-tile loader, the small-job kernel, the standalone composite kernels)

@@ -479,19 +479,14 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 const int row = lane_id_opaque();
                 const bool valid = row < rows_valid;
                 float th[84];
-                {
+                auto load_th = [&]() {          // (the one-latent-at-a-time path keeps the point's flow parameters in registers over its loop)
                     const f32x4* tp = reinterpret_cast<const f32x4*>(act + row * LD);
 #pragma unroll
-                    for (int q = 0; q < 18; ++q) {
-                        const f32x4 v = tp[q];
+                    for (int q = 0; q < 21; ++q) {
+                        const f32x4 v = tp[q < 18 ? q : kThetaRgb / 4 + (q - 18)];
                         th[q * 4 + 0] = v[0]; th[q * 4 + 1] = v[1]; th[q * 4 + 2] = v[2]; th[q * 4 + 3] = v[3];
                     }
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const f32x4 v = tp[kThetaRgb / 4 + q];
-                        th[72 + q * 4 + 0] = v[0]; th[72 + q * 4 + 1] = v[1]; th[72 + q * 4 + 2] = v[2]; th[72 + q * 4 + 3] = v[3];
-                    }
-                }
+                };
                 float zval = 0.f, dist = 0.f;
                 if (MODE == 0) {
                     zval = rowinfo[row * 4 + 3];
@@ -503,7 +498,7 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 auto flow_phase = [&](auto fast_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     using M = Num<FAST>;
-                    for (int k = wave; k < K; k += kWv) {
+                    auto one = [&](const int k) {
                         const f32x4 e = *reinterpret_cast<const f32x4*>(f_eps + k * 4);
                         float z[3] = {e[0] * r_std[0] + r_mean[0], e[1] * r_std[1] + r_mean[1], e[2] * r_std[2] + r_mean[2]};  // MOD:206/251
                         float a = e[3] * a_std + a_mean;                                               // MOD:200/239
@@ -543,6 +538,92 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                                 cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar * tot;
                             }
                         }
+                    };
+                    // two latents of the wave at a time (hardware-transcendental flavour, i.e. from 16 latents on): the plain multiplies and adds
+                    // of the pair go out as packed fp32 instructions, the wave scans / sums of the two composites interleave.  Component
+                    // for component the operations of one(): the same values, summed into the entropy terms in the same order.
+                    auto two = [&](const int k0, const int k1) {
+                        using M2 = Num2;
+                        const f32x4 e0 = *reinterpret_cast<const f32x4*>(f_eps + k0 * 4), e1 = *reinterpret_cast<const f32x4*>(f_eps + k1 * 4);
+                        f32x2 z[3], a;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { f32x2 ec; ec[0] = e0[c]; ec[1] = e1[c]; z[c] = ec * r_std[c] + r_mean[c]; }
+                        { f32x2 ec; ec[0] = e0[3]; ec[1] = e1[3]; a = ec * a_std + a_mean; }
+                        // the point's 84 flow parameters as register PAIRS, read from its LDS row in every iteration: a packed instruction takes either
+                        // half of a pair for both components (op_sel) only when the pair is formed in the loop body - hoisted out of the loop the
+                        // compiler keeps a broadcast copy (x, x) of every parameter, 168 registers, and spills.  21 conflict-free ds_read_b128 per ~460
+                        // vector instructions, on a pipe the flow phase does not otherwise use
+                        f32x2 thp[42];
+                        {
+                            asm volatile("" ::: "memory");          // the reads below belong to THIS iteration (nothing for the compiler to hoist)
+                            const f32x4* tp = reinterpret_cast<const f32x4*>(act + row * LD);
+#pragma unroll
+                            for (int q = 0; q < 21; ++q) {
+                                const f32x4 v = tp[q < 18 ? q : kThetaRgb / 4 + (q - 18)];
+                                thp[q * 2 + 0] = __builtin_shufflevector(v, v, 0, 1); thp[q * 2 + 1] = __builtin_shufflevector(v, v, 2, 3);
+                            }
+                        }
+                        f32x2 ldr, lda;
+                        flows_fwd2<TRAIN>(thp, z, a, ldr, lda);
+                        if (f_raw != nullptr || f_sraw != nullptr) {
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const int k = c ? k1 : k0;
+                                f32x4 o; o[0] = z[0][c]; o[1] = z[1][c]; o[2] = z[2][c]; o[3] = a[c];
+                                if (f_raw != nullptr && valid) *reinterpret_cast<f32x4*>(f_raw + ((p0 + row) * (int64_t)K + k) * 4) = o;
+                                if (f_sraw != nullptr) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(f_sraw + (k * kTileM + row) * 4));
+                            }
+                        }
+                        const f32x2 sp_a = M2::softplus(a);
+                        if (TRAIN && valid) {
+                            const f32x2 ta = lda + (a - sp_a);
+                            const f32x2 tr = ldr + (((z[0] + z[1]) + z[2]) - 2.f * ((M2::softplus(z[0]) + M2::softplus(z[1])) + M2::softplus(z[2])));
+                            ent_a_sum += ta[0]; ent_a_sum += ta[1];
+                            ent_r_sum += tr[0]; ent_r_sum += tr[1];
+                        }
+                        if (MODE == 0) {
+                            f32x2 ea = M2::exp(-sp_a * dist);
+                            if (!valid) ea = 1.f;
+                            const f32x2 alpha = 1.f - ea;
+                            const f32x2 xk = (1.f - alpha) + 1e-10f;
+                            const f32x2 g0 = M2::sigmoid(z[0]), g1 = M2::sigmoid(z[1]), g2 = M2::sigmoid(z[2]);
+                            f32x2 incl, excl;
+                            { float i0, x0, i1, x1; comp_scan_mul(xk[0], i0, x0); comp_scan_mul(xk[1], i1, x1); incl[0] = i0; incl[1] = i1; excl[0] = x0; excl[1] = x1; }
+                            float* cp0 = comp + k0 * 8; float* cp1 = comp + k1 * 8;
+                            f32x2 Tcar; Tcar[0] = cp0[5]; Tcar[1] = cp1[5];
+                            const f32x2 Tex = Tcar * excl;
+                            const f32x2 wgt = alpha * Tex;
+                            if (f_weights != nullptr && valid) {
+                                f_weights[(p0 + row) * (int64_t)K + k0] = wgt[0];
+                                f_weights[(p0 + row) * (int64_t)K + k1] = wgt[1];
+                            }
+                            if (f_at != nullptr) {
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) {
+                                    f32x2 at; at[0] = ea[c]; at[1] = Tex[c];
+                                    __builtin_nontemporal_store(at, reinterpret_cast<f32x2*>(f_at + ((c ? k1 : k0) * kTileM + row) * 2));
+                                }
+                            }
+                            const f32x2 w0 = wgt * g0, w1 = wgt * g1, w2 = wgt * g2, wd = wgt * zval;
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const float s0 = comp_sum(w0[c]), s1 = comp_sum(w1[c]), s2 = comp_sum(w2[c]);
+                                const float sd = comp_sum(wd[c]), sa = comp_sum(wgt[c]);
+                                const float tot = comp_last(incl[c]);
+                                float* cp = c ? cp1 : cp0;
+                                if (lane == 0) {
+                                    cp[0] += s0; cp[1] += s1; cp[2] += s2; cp[3] += sd; cp[4] += sa; cp[5] = Tcar[c] * tot;
+                                }
+                            }
+                        }
+                    };
+                    if constexpr (FAST) {
+                        int k = wave;
+                        for (; k + kWv < K; k += 2 * kWv) two(k, k + kWv);
+                        if (k < K) { load_th(); one(k); }
+                    } else {
+                        load_th();
+                        for (int k = wave; k < K; k += kWv) one(k);
                     }
                 };
                 const bool fast = (f_flags & CFNERF_F_FLOW_MATH_SET) ? (f_flags & CFNERF_F_FLOW_MATH_FAST) != 0 : K >= kFastFlowsK;     // wave-uniform
