@@ -311,7 +311,10 @@ def test_get_rays_and_ndc_rays_helpers_vs_reference_golden(golden):
 
 @pytest.mark.parametrize("W,K,N,ndc", [(256, 4, 96, True), (256, 8, 40, False), (512, 16, 24, True), (128, 2, 33, True),
                                        (192, 3, 20, True), (320, 4, 12, False), (384, 2, 10, True), (448, 3, 9, True), (128, 128, 5, True),
-                                       (256, 96, 4, False)])
+                                       (256, 96, 4, False),
+                                       # from 16 latents on a wave takes its latents two at a time (flows_fwd2) and a left-over one alone: odd counts per
+                                       # wave, waves with different counts (4 waves: K = 17, 18, 19, 23; 8 waves at W = 512: K = 20, 24)
+                                       (128, 17, 6, True), (64, 18, 7, False), (128, 19, 5, True), (64, 23, 5, True), (512, 24, 4, True), (512, 20, 4, False)])
 def test_render_vs_oracle(W, K, N, ndc):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
     _, kw_train, kw_test, model, p, _ = build_model(cfg, 300 + W + K, no_ndc=not ndc)

@@ -106,7 +106,9 @@ def test_train_step_vs_reference_golden(golden, tag):
                                    # the reference's default K_samples (64, RUN:631); incl. the authors' W = 512 / h_alpha = 64
                                    (256, 16, 12), (256, 32, 6), (256, 64, 4), (512, 32, 4), (64, 64, 5), (128, 16, 9),
                                    # netwidth: every multiple of 64; K above the reference's default of 64
-                                   (192, 4, 20), (320, 3, 12), (384, 5, 8), (448, 2, 10), (128, 128, 3), (256, 100, 2)])
+                                   (192, 4, 20), (320, 3, 12), (384, 5, 8), (448, 2, 10), (128, 128, 3), (256, 100, 2),
+                                   # latent pairs + a left-over latent per wave in the forward's flow phase (4 waves / 8 waves)
+                                   (128, 17, 5), (64, 22, 6), (512, 20, 3)])
 def test_gradients_vs_oracle(W, K, N):
     cfg = O.OracleCfg(netwidth=W, K_samples=K, h_alpha_size=64 if W == 512 else 32)
     _, kw_train, _, model, p, _ = build_model(cfg, 500 + W + K)
