@@ -115,12 +115,15 @@ def hip_relu_masks(net, P, rows=None):
 
 
 def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, beta1, lindisp=False, white_bkgd=False,
-                                   max_flip_frac=2e-4, t_vals=None, f64=True):
+                                   max_flip_frac=2e-4, t_vals=None, f64=True, loss_grad_at=None):
     """(scalars, grads, ret, n_flips): the oracle's train step differentiated on the ReLU masks of the HIP forward that
     was just run on the same inputs, after checking that those masks differ from the oracle's own only by rounding.
     `f64` (default): the differentiation runs in float64, so the reference gradient carries no fp32 noise of its own (the
     transmittance adjoint divides by ~1e-10 factors: an fp32 oracle is as noisy there as the kernels) and the per-tensor
-    bounds of grad_close_tight measure the HIP path alone."""
+    bounds of grad_close_tight measure the HIP path alone.
+    `loss_grad_at` (an rgb_map, e.g. the HIP forward's): the cotangent of the backward is the fp64 loss gradient evaluated at THAT rgb_map
+    instead of at the oracle's own (returned as ret["d_loss_d_rgb_map"]) - the reference of a backward run in isolation from the loss's
+    steepness (K = 2: tests/test_hip_train.py); every calibration term below is then taken with that same cotangent."""
     S = 128 if t_vals is None else int(t_vals.shape[0])
     P = packed.shape[0] * S
     acts, masks = hip_relu_masks(net, P)
@@ -154,7 +157,11 @@ def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 
             O.latent_tap = None
         L = O.train_loss(ret["rgb_map"], d(target), ret["loss_entropy"], cfg.K_samples, beta1)
         keys = [k for k in q]
-        (G,) = torch.autograd.grad(L["loss"], ret["rgb_map"], retain_graph=True)
+        if loss_grad_at is None:
+            (G,) = torch.autograd.grad(L["loss"], ret["rgb_map"], retain_graph=True)
+        else:
+            r_at = d(loss_grad_at).detach().clone().requires_grad_(True)
+            (G,) = torch.autograd.grad(O.train_loss(r_at, d(target), ret["loss_entropy"].detach(), cfg.K_samples, beta1)["loss"], r_at)
         outs, cots = [ret["rgb_map"]], [G]
         if beta1:
             outs.append(ret["loss_entropy"]); cots.append(torch.tensor(float(beta1), dtype=torch.float64))
@@ -163,6 +170,7 @@ def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 
         scal = {k: float(v.detach()) for k, v in L.items()}
         scal["loss_entropy"] = float(ret["loss_entropy"].detach())
         ret = {k: v.detach() for k, v in ret.items() if v is not None}
+        ret["d_loss_d_rgb_map"] = G.detach()
         # Calibration of the bound, per tensor and per case.  (1) the SAME differentiation in fp32: what a straightforward fp32
         # implementation of this math delivers on THESE inputs.  (2) the conditioning of the case: a correct fp32 forward returns
         # rgb_map within ~5e-7, which moves the loss gradient d loss / d rgb_map by ~2e-6 of its largest entry (measured: HIP 1.7e-6,
@@ -174,7 +182,15 @@ def oracle_train_step_on_hip_masks(net, p, packed, target, cfg, ea, er, t_rand, 
         gen = torch.Generator().manual_seed(0)
         Gp = G + 2e-6 * float(G.abs().max()) * (torch.rand(G.shape, generator=gen, dtype=torch.float64) * 2 - 1)
         gp = torch.autograd.grad(outs, [q[k] for k in keys], [Gp] + cots[1:], retain_graph=True, allow_unused=True)
-        _, g32, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
+        if loss_grad_at is None:
+            _, g32, _ = O.train_step(p, packed, target, cfg, ea, er, t_rand, beta1, lindisp, white_bkgd, t_vals=t_vals)
+        else:                                            # the same fp32 differentiation, fed the same cotangent
+            q32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            r32 = O.render_rays(q32, packed, cfg, ea, er, True, t_rand, lindisp, white_bkgd, t_vals=t_vals)
+            o32, c32 = [r32["rgb_map"]], [G.float()]
+            if beta1:
+                o32.append(r32["loss_entropy"]); c32.append(torch.tensor(float(beta1)))
+            g32 = dict(zip(keys, torch.autograd.grad(o32, [q32[k] for k in keys], c32, allow_unused=True)))
         # Tensors of a few elements (the base Gaussians: each entry is ONE sum over all (point, latent) contributions, which largely
         # cancel) get no averaging over entries: with a single perturbation draw the ratio error / noise is a ratio of two
         # half-normal variables and exceeds 10 in ~6 % of the cases (found by the CFNERF_FUZZ_SEEDS soak: 9 % of 140 random
