@@ -586,7 +586,9 @@ __device__ __forceinline__ void dw_store_tile(const DwTile& t, gf_ptr out, const
 constexpr int kDwThreads = 512;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // a function's arguments arrive in VECTOR registers: tell the compiler they are wave-uniform, or every buffer load built
-// from them is wrapped in a waterfall loop (cdna_hip_programming.md T20)
+// from them is wrapped in a waterfall loop (cdna_hip_programming.md T20).  (The tile bodies below were `noinline` functions in
+// rounds 3-4 - 48 to 220 callee-save scratch stores and loads per call; inlined since round 5 the fp32 kernel holds 171 VGPRs and no
+// scratch, and the launch is 7 us (W 256) / 12 us (W 512) shorter; the readfirstlanes are then no-ops.)
 template <class T>
 __device__ __forceinline__ T* uniform_ptr(T* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -602,8 +604,8 @@ __device__ __forceinline__ void ds_wait_stage(int n_w) {   // at most n_w of thi
 }
 
 template <int PREC, int ARR>
-__device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
-                                                      float* __restrict__ partials_, int64_t n_params_) {
+__device__ __forceinline__ void dw_big_body(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
+                                            float* __restrict__ partials_, int64_t n_params_) {
     const DwTile* __restrict__ tiles = uniform_ptr(tiles_);
     const DwBlock* __restrict__ blocks = uniform_ptr(blocks_);
     float* __restrict__ partials = uniform_ptr(partials_);
@@ -804,7 +806,7 @@ __device__ __attribute__((noinline)) void dw_big_body(const DwTile* __restrict__
 // 8 g + 4 h + e for A and B alike).  Wave arrangement as above: 2 x 4 (wave = n-tiles 4 wn .. 4 wn + 3 x k-tiles 2 wk, 2 wk + 1) or, for
 // N <= 128, 1 x 8 (n-tiles 0 .. 3 x k-tile wk).  The output tile is natural (no interleaving): dW[n0 + 32 tn' + frag_row][k0 + 32 tk' + lane & 31].
 template <int ARR>
-__device__ __attribute__((noinline)) void dw_big_body_q4(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
+__device__ __forceinline__ void dw_big_body_q4(const DwTile* __restrict__ tiles_, const DwBlock* __restrict__ blocks_,
                                                          float* __restrict__ partials_, int64_t n_params_) {
     const DwTile* __restrict__ tiles = uniform_ptr(tiles_);
     const DwBlock* __restrict__ blocks = uniform_ptr(blocks_);
