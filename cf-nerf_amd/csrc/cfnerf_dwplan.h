@@ -112,24 +112,57 @@ inline void make_blocks(std::vector<DwBlock>& blocks, std::vector<DwTile>& tiles
 
 // Split counts of the big tiles: one block per CU in total (every block of the launch has the same footprint, so the
 // hardware places exactly one per CU whatever the mix), points shared out so that every block takes about the same time:
-// a 1 x 8 block (N <= 128) issues half the MFMAs per stage of a 2 x 4 block but pays the same fixed cost per stage, ~0.59
-// of its time per point (measured), so it gets proportionally more points.
+// a 1 x 8 block (N <= 128: the views layer) issues half the MFMAs per stage of a 2 x 4 block but pays the same fixed cost per stage, so it
+// gets proportionally more points: 0.59 of a 2 x 4 block's time per point when both kinds stage row-major operands (measured in round 3;
+// still the bf16x3 mode and ragged batches), 0.53 against the Q4 bodies of the 2 x 4 tiles (round 5, same-box A/B over 0.50 / 0.54 / 0.59 /
+// 0.66: the default network's nine tiles then split 8 x 30 + 16 instead of 6 x 30 + 2 x 29 + 18 - with 0.59 the blocks of the two 29-split
+// tiles ran 3.4 % longer than everything else: weight-gradient stage 1.224 -> 1.193 ms at C2).
+//
+// ROUNDS (round 5).  With one block per CU the longest block is the launch: 34 equal tiles on 256 CUs (W = 512) split 18 x 8 + 16 x 7 and the
+// 7-split tiles' blocks run 14 % longer than the other half of the chip - the launch sat 7.6 % above its even share.  With two blocks per CU
+// (2 x 15 + 32 x 16 ... every CU takes a long and then a shorter block, the hardware hands the next block of the list to the CU that frees
+// up first) the shares even out, at the price of one more block prologue + 256-KB partial store per CU, ~23 us = ~100 points' worth
+// (measured: W = 512 weight-gradient stage 2.308 -> 2.194 ms with two rounds; C2, whose nine tiles already split evenly, 1.195 -> 1.218).
+// The plan is made for 1, 2 and 3 rounds and the one with the shortest modelled makespan kept.
+constexpr double kDwBlockOverheadPoints = 100.0;
+inline double big_split_makespan(const std::vector<DwTile>& tiles, const std::vector<int>& nsplit, int n_cu, int64_t P, double arr1) {
+    std::vector<double> len;                                 // block lengths in 2 x 4-tile points, longest first = the dispatch order
+    for (size_t i = 0; i < tiles.size(); ++i)
+        for (int s = 0; s < nsplit[i]; ++s)
+            len.push_back((tiles[i].gk == 1 ? arr1 : 1.0) * (double)((P + nsplit[i] - 1) / nsplit[i]) + kDwBlockOverheadPoints);
+    std::sort(len.begin(), len.end(), [](double a, double b) { return a > b; });
+    std::vector<double> cu((size_t)n_cu, 0.0);               // a free CU takes the next block of the list
+    for (double l : len) *std::min_element(cu.begin(), cu.end()) += l;
+    return *std::max_element(cu.begin(), cu.end());
+}
 inline void balance_big_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P, int max_split) {
     if (tiles.empty()) return;
-    auto cost = [](const DwTile& t) { return t.gk == 1 ? 0.59 : 1.0; };
+    bool q4 = false;
+    for (const DwTile& t : tiles) q4 = q4 || t.lay == 3;
+    const double arr1 = q4 ? 0.53 : 0.59;
+    auto cost = [arr1](const DwTile& t) { return t.gk == 1 ? arr1 : 1.0; };
     double total = 0;
     for (const DwTile& t : tiles) total += cost(t);
     int cap = max_split;
     while (cap > 1 && P / cap < 512) --cap;                  // at least 512 points per block
-    int used = 0;
-    for (DwTile& t : tiles) { t.nsplit = std::max(1, std::min(cap, (int)(n_cu * cost(t) / total))); used += t.nsplit; }
-    while (used < n_cu) {                                    // hand the remaining CUs to the tiles whose blocks are longest
-        DwTile* best = nullptr;
-        for (DwTile& t : tiles)
-            if (t.nsplit < cap && (!best || cost(t) / t.nsplit > cost(*best) / best->nsplit)) best = &t;
-        if (!best) break;
-        ++best->nsplit; ++used;
+    std::vector<int> best_split;
+    double best_span = 0;
+    for (int rounds = 1; rounds <= 3; ++rounds) {
+        const int slots = n_cu * rounds;
+        std::vector<int> ns(tiles.size());
+        int used = 0;
+        for (size_t i = 0; i < tiles.size(); ++i) { ns[i] = std::max(1, std::min(cap, (int)(slots * cost(tiles[i]) / total))); used += ns[i]; }
+        while (used < slots) {                               // hand the remaining slots to the tiles whose blocks are longest
+            int best = -1;
+            for (size_t i = 0; i < tiles.size(); ++i)
+                if (ns[i] < cap && (best < 0 || cost(tiles[i]) / ns[i] > cost(tiles[(size_t)best]) / ns[(size_t)best])) best = (int)i;
+            if (best < 0) break;
+            ++ns[(size_t)best]; ++used;
+        }
+        const double span = big_split_makespan(tiles, ns, n_cu, P, arr1);
+        if (best_split.empty() || span < best_span * 0.995) { best_split = ns; best_span = span; }      // (more rounds only for a clear gain)
     }
+    for (size_t i = 0; i < tiles.size(); ++i) tiles[i].nsplit = best_split[i];
 }
 
 // Split counts of the small jobs.  The launch is HBM-bound (a block streams 32 x (a_ld + b_ld) floats per stage), two

@@ -124,6 +124,7 @@ CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu
     const size_t step = size_t(1) << 36;
     float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
+    q.q4 = P % kTileM == 0;                                // as the fp32 product does for whole tiles (cfnerf_abi.hip): the Q4 bodies and their split costs
     DwHost H;
     int n_wide = 0, ns_max = 0;
     const char* why = build_dw_plan(*cfg, L, q, P, n_cu, H, &n_wide, &ns_max);

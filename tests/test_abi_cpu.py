@@ -367,9 +367,17 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
         for g in range(int(t[ti, 7])):
             assert seg_n[seg_of[int(sd[ti, g])]] >= nsplit
     n_big = int((b[:, 0] <= 1).sum())
-    assert n_big <= max(n_cu, nt), (n_big, n_cu)
+    # one block per CU in total, or (round 5) two or three per CU where whole rounds even the shares out: cfnerf_dwplan.h, balance_big_splits
+    assert n_big <= 3 * max(n_cu, nt), (n_big, n_cu)
     if P >= 512 * 64:
         assert n_big >= n_cu - 8, (n_big, n_cu)            # enough points: the launch fills the chip
+    # the two headline networks on the 256 CUs of an MI355X (measured splits): nine tiles of W = 256 share the chip evenly in ONE
+    # round (eight 2 x 4 tiles x 30 blocks + the 1 x 8 views tile x 16); the 34 equal tiles of W = 512 need TWO rounds (15 / 16 blocks per tile)
+    big_ns = sorted(abs(int(x)) for ti, x in enumerate(ns) if t[ti, 0])
+    if (W, D, P, n_cu) == (256, 8, 131072, 256):
+        assert big_ns == [16] + [30] * 8, big_ns
+    if (W, D, P, n_cu) == (512, 8, 65536, 256):
+        assert n_big in (510, 511, 512) and set(big_ns) <= {15, 16}, (n_big, big_ns)
 
 
 def test_bench_gpus_n_without_enough_gpus_fails_cleanly():
