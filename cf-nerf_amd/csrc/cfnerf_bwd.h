@@ -82,6 +82,7 @@ struct BwdPlan {
     bool q4 = false;                                      // ... and the layout of the wide streams (Stash::q4) they describe
     int n_blocks_wide = 0;                                // blocks[0, n_blocks_wide): 2 x 4 tiles; the rest: 1 x 8 tiles
     hipEvent_t ev_early = nullptr;                        // recorded once the "early" tensors' gradients are final
+    bool early_wanted = false;                            // the caller has asked for the early ranges (cfnerf_grad_early_ranges): reduce them before the small jobs
     std::vector<int64_t> early_off, early_cnt;            // flat ranges of grad_flat that are final at ev_early (merged, sorted)
     void release() {
         for (DwHost& h : host) { if (h.uploaded) (void)hipEventDestroy(h.uploaded); h.uploaded = nullptr; }

@@ -234,7 +234,10 @@ CFNERF_API int cfnerf_composite_bwd(const float* raw, const float* z_vals, const
  * launches alone - is final BEFORE the small-job launch that ends cfnerf_render_bwd.  cfnerf_grad_early_ranges
  * reports those flat ranges (they depend on the configuration only; available after the first cfnerf_render_bwd);
  * cfnerf_stream_wait_grad_early makes `waiter` (e.g. the communication stream) wait for the event recorded at
- * that point of the LAST cfnerf_render_bwd, so the all-reduce of those ranges runs while the rest still computes. */
+ * that point of the LAST cfnerf_render_bwd, so the all-reduce of those ranges runs while the rest still computes.
+ * The early point exists from the first cfnerf_render_bwd AFTER a call of cfnerf_grad_early_ranges on (a caller that never asks
+ * gets one reduction launch at the end instead of two); before that the event fires when the whole gradient is final - a
+ * waiter is always correct, only not early.                                                                                 */
 CFNERF_API int cfnerf_grad_early_ranges(cfnerf_model* m, int64_t* offsets, int64_t* counts, int max_ranges);
 CFNERF_API int cfnerf_stream_wait_grad_early(cfnerf_model* m, cfnerf_stream waiter);
 

@@ -849,6 +849,31 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
         check_all_grads(net, grad, grads, what)
 
 
+def test_one_reduction_launch_equals_the_two_phase_one_bit_for_bit():
+    """A caller that never asks for the early gradient ranges gets ONE weight-gradient reduction launch after the small jobs; once
+    cfnerf_grad_early_ranges has been called (the two-bucket exchange) the early tensors are reduced before them.  Same sums in the same
+    order: the gradient is bit-identical, and the ranges are available before and after the switch."""
+    import ctypes as C
+    from cfnerf_amd import _lib as L
+    cfg = O.OracleCfg(netwidth=128, K_samples=4)
+    _, kw_train, _, model, p, _ = build_model(cfg, 31)
+    net = model.module
+    rng = np.random.default_rng(3)
+    N = 96
+    rays, (H, Wd, focal) = fern_rays(rng, N)
+    kw = dict(t_rand=torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32).to(DEV),
+              eps=torch.tensor(rng.standard_normal((4, 4)), dtype=torch.float32).to(DEV))
+    target = torch.tensor(rng.uniform(0, 1, (N, 3)), dtype=torch.float32).to(DEV)
+    tr = TR.Trainer(net, beta1=0.05)
+    g_one = tr.forward_backward(H, Wd, focal, rays.to(DEV), target, **kw).clone()
+    offs, cnts = (C.c_int64 * 64)(), (C.c_int64 * 64)()
+    k = L.lib().cfnerf_grad_early_ranges(net.handle, offs, cnts, 64)
+    assert k > 0 and sum(cnts[i] for i in range(k)) > 0.5 * net.n_params
+    g_two = tr.forward_backward(H, Wd, focal, rays.to(DEV), target, **kw).clone()
+    assert torch.equal(g_one, g_two)
+    assert L.lib().cfnerf_stream_wait_grad_early(net.handle, L.stream()) == 0
+
+
 def step_link_by_link(c, name):
     """Links (a) - (c) of test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness on a fuzz_case: the forward, the loss kernel at ITS
     OWN input and the fused backward fed the fp64 loss gradient, each against fp64.  Returns what link (d) needs."""
