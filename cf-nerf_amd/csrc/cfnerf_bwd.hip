@@ -203,10 +203,10 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                 }
             }
         }
-        // ---- back to front: suffix sums of g w as a reverse wave scan + a carry (see tail_bwd_kernel)
-        float sufcar[KG];
+        // ---- back to front: the transmittance adjoint as a reverse affine wave scan + a carry (see tail_bwd_kernel, comp_adjoint_D)
+        float cg[KG], cx[KG], cD[KG];                        // (g, x, D) of the first sample of the chunk behind (comp_adjoint_D, cfnerf_device.h)
 #pragma unroll
-        for (int q = 0; q < KG; ++q) sufcar[q] = 0.f;
+        for (int q = 0; q < KG; ++q) { cg[q] = 0.f; cx[q] = 0.f; cD[q] = 0.f; }
         for (int ch = nch - 1; ch >= 0; --ch) {
             const int s = ch * 64 + lane;
             const bool valid = s < S;
@@ -252,12 +252,7 @@ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict
                     float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;
                     g += Ga;
                     g += dwv[q];
-                    const float gw = valid ? g * w : 0.f;
-                    float excl, tot;
-                    comp_suffix(gw, excl, tot);
-                    const float suffix = excl + sufcar[q];
-                    sufcar[q] += tot;
-                    const float dalpha = g * Tt - suffix * t_rcp(xk);
+                    const float dalpha = Tt * comp_adjoint_D(valid ? g : 0.f, xk, cg[q], cx[q], cD[q]);      // = g T - suffix / x, carried as the cancelled quantity
                     const float sg = t_sigmoid(rv[3]);                                 // softplus'
                     f32x4 o;
                     o[0] = G0 * w * c0 * (1.f - c0); o[1] = G1 * w * c1 * (1.f - c1); o[2] = G2 * w * c2 * (1.f - c2);

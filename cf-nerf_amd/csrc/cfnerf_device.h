@@ -656,17 +656,6 @@ __device__ __forceinline__ float wave_scan_mul(float v) {
     }
     return v;
 }
-// inclusive additive scan from the HIGH lane down (suffix sum)
-__device__ __forceinline__ float wave_scan_add_rev(float v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float t = __shfl_down(v, d, 64);
-        if (lane + d < 64) v += t;
-    }
-    return v;
-}
-
 // ---- the same scans / reductions on DPP (data-parallel primitives: the cross-lane move is a modifier of a vector-ALU instruction,
 // no LDS round trip).  __shfl_* compile to ds_bpermute_b32 - an LDS instruction with ~100 cycles of latency - and a scan is a chain
 // of six of them; the gfx9 DPP scan is row_shr:1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 to carry the
@@ -707,21 +696,41 @@ __device__ __forceinline__ void comp_scan_mul(float xk, float& incl, float& excl
 }
 __device__ __forceinline__ float comp_sum(float x) { return kUseDpp ? wave_sum_dpp(x) : wave_sum(x); }
 __device__ __forceinline__ float comp_last(float incl) { return kUseDpp ? wave_last(incl) : __shfl(incl, 63, 64); }
-// exclusive suffix sum (lanes ABOVE this one) and the total, without a subtraction (the suffix is later divided by ~1e-10 for opaque samples)
-__device__ __forceinline__ void comp_suffix(float gw, float& excl, float& tot) {
-    const int lane = lane_id();
-    if (kUseDpp) {
-        // reverse the lane order (one LDS permute), prefix-scan on DPP, shift by one lane, permute back: 2 LDS round trips, not 8
-        const float rev = __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) * 4, __float_as_int(gw)));
-        const float incl_r = wave_scan_add_dpp(rev);
-        tot = wave_last(incl_r);
-        excl = __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) * 4, __float_as_int(wave_prev_dpp(incl_r, 0.f))));
-    } else {
-        const float incl = wave_scan_add_rev(gw);
-        excl = __shfl_down(incl, 1, 64);
-        if (lane == 63) excl = 0.f;
-        tot = __shfl(incl, 0, 64);
-    }
+// ---- the adjoint of the transmittance product (RUN:443), carried as the CANCELLED quantity itself (round 6) --------------------------------
+// d loss / d alpha_s = g_s T_s - (sum_{j>s} g_j w_j) / x_s   (g = d loss / d w, x = 1 - alpha + 1e-10, T_{s+1} = T_s x_s: what torch's
+// cumprod backward evaluates and what rounds 1-5 evaluated here) is the difference of two terms of size |g| T_s that agree to 2-3 digits
+// wherever the samples behind s have the colour of s (any opaque surface).  Every T_j carries its own rounding history: relative to the
+// exact product, rho_j.  The computed gradient is the EXACT gradient of sum_j g_j w_j (1 + rho_j) - and how far that is from the exact
+// one depends on how rho varies ALONG THE RAY, not on its size: torch's sequential cumprod makes rho a random walk with 3e-8 steps
+// (neighbours share all but one rounding: the error is ~rho x the exact gradient), the wave scan of the forward gives every lane its own
+// product tree (white noise of ~1e-7: the error is 1e-7 x the UNCANCELLED terms).  Measured on single rays (tests/tools/density_bisect.py,
+// profiles/r06_density_bisect.txt): the kernel's formula in fp64 fed the stashed fp32 T reproduces the kernel's error (bias sums of the
+// density heads 1e-4 of their largest entry where torch's fp32 autograd is at 3e-6 .. 9e-6) - the product scan's T, nothing else.
+// So the recurrence is written for D_s = g_s - R_{s+1}, R_{s+1} = what the samples behind s render for the cotangent g (the quantity
+// that is left after the cancellation):
+//     d loss / d alpha_s = T_s D_s,      D_s = (g_s - g_{s+1}) + x_{s+1} D_{s+1} - 1e-10 g_{s+1},      D behind the last sample = 0
+// (R_{s+1} = g_{s+1} alpha_{s+1} + x_{s+1} R_{s+2} with alpha = 1 - x + 1e-10).  Its inputs are colour DIFFERENCES of neighbouring samples,
+// T enters once as a plain factor (its white noise stays relative to the result), nothing is divided by x ~ 1e-10.  In exact arithmetic
+// the same number as the suffix form.  One suffix scan of affine maps y -> a y + b over the wave (lane order reversed by one LDS permute,
+// then the gfx9 DPP prefix-scan sequence) + (g, x, D) of the first sample of the chunk behind as the carry.
+__device__ __forceinline__ void wave_scan_affine_dpp(float& a, float& b) {      // lane r: the composition of the maps of lanes r, r - 1, ... 0
+#define CFN_AFF(CTRL, RM) { const float as = dpp_mov<CTRL, RM, 0xf>(1.f, a), bs = dpp_mov<CTRL, RM, 0xf>(0.f, b); b = __builtin_fmaf(a, bs, b); a = a * as; }
+    CFN_AFF(0x111, 0xf) CFN_AFF(0x112, 0xf) CFN_AFF(0x114, 0xf) CFN_AFF(0x118, 0xf) CFN_AFF(0x142, 0xa) CFN_AFF(0x143, 0xc)
+#undef CFN_AFF
+}
+// lane = sample of a 64-sample chunk, chunks walked back to front.  g: d loss / d w_s (0 for a lane past the ray's last sample), xk: the
+// forward's cumprod factor; car_*: (g, x, D) of the first sample of the chunk behind (0, 0, 0 behind the ray's end), updated to this chunk's.
+__device__ __forceinline__ float comp_adjoint_D(const float g, const float xk, float& car_g, float& car_x, float& car_D) {
+    static_assert(kUseDpp, "the affine scan is written on DPP");
+    const int ridx = (63 - lane_id()) * 4;
+    const float rg = __int_as_float(__builtin_amdgcn_ds_bpermute(ridx, __float_as_int(g)));      // reversed: lane r holds sample 63 - r
+    const float rx = __int_as_float(__builtin_amdgcn_ds_bpermute(ridx, __float_as_int(xk)));
+    const float gn = wave_prev_dpp(rg, car_g), xn = wave_prev_dpp(rx, car_x);                      // sample s + 1
+    float a = xn, b = __builtin_fmaf(-1e-10f, gn, rg - gn);
+    wave_scan_affine_dpp(a, b);
+    const float Dr = __builtin_fmaf(a, car_D, b);
+    car_D = wave_last(Dr); car_g = wave_last(rg); car_x = wave_last(rx);
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(ridx, __float_as_int(Dr)));
 }
 
 // gamma(v): channel c of the encoding of a 3-vector (HLP:42-51): c<3 identity, then per

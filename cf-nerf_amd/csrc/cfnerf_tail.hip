@@ -149,7 +149,7 @@ __device__ __forceinline__ void store_gtheta_row(float* __restrict__ row, const 
 __global__ __launch_bounds__(kThreads, 2)
 void tail_bwd_kernel(const TailArgs A) {
 #pragma clang fp contract(fast)
-    __shared__ float carry[kWaves][kMaxK];
+    __shared__ float carry[kWaves][kMaxK][3];              // per latent: (g, x, D) of the first sample of the chunk behind (comp_adjoint_D)
     // merge (ksplit 2 or 4, so a ray's parts are waves of ONE workgroup): the parts past the first publish their 84 partial sums per
     // sample here and the first adds them before it writes the row - one g_theta part leaves the kernel, and backward-data neither reads
     // a second [P,128] array nor writes the sum back (K = 64: +60 MB read, +65 MB written, +4.9 % of that kernel by counters).
@@ -176,7 +176,7 @@ void tail_bwd_kernel(const TailArgs A) {
     const float a_mean = A.flat[0], a_std = A.flat[1];
     const float r_mean[3] = {A.flat[2], A.flat[3], A.flat[4]};
     const float r_std[3] = {A.flat[5], A.flat[6], A.flat[7]};
-    for (int k = lane; k < K; k += 64) carry[wave][k] = 0.f;
+    for (int k = lane; k < K; k += 64) { carry[wave][k][0] = 0.f; carry[wave][k][1] = 0.f; carry[wave][k][2] = 0.f; }
     float gms[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) gms[i] = 0.f;
@@ -236,14 +236,13 @@ void tail_bwd_kernel(const TailArgs A) {
             const float w = alpha * Tt;
             float g = (G0 * c0 + G1 * c1 + G2 * c2) + Gd * zv;                 // d loss / d w_s
             if (wb) g -= (G0 + G1 + G2);                                       // rgb_map += 1 - acc  (RUN:452)
-            const float gw = valid ? g * w : 0.f;
-            const float car = carry[wave][k];
-            float excl, tot;
-            comp_suffix(gw, excl, tot);                                        // sum over the samples above s of this chunk, and the chunk's total
-            const float suffix = excl + car;                                   // sum over samples > s of the ray
-            if (lane == 0) carry[wave][k] = car + tot;
+            // d loss / d alpha = T D with D = g_s - (what the samples behind s render for g), carried by its own recurrence (comp_adjoint_D,
+            // cfnerf_device.h: rounds 1-5 formed g T - suffix / x from the forward's T and lost 1-2 digits per ray to the product scan's noise)
             const float xk = (1.f - alpha) + 1e-10f;                           // cumprod factor of RUN:443
-            const float dalpha = g * Tt - suffix * t_rcp(xk);
+            float cg = carry[wave][k][0], cx = carry[wave][k][1], cD = carry[wave][k][2];
+            const float Dv = comp_adjoint_D(valid ? g : 0.f, xk, cg, cx, cD);
+            if (lane == 0) { carry[wave][k][0] = cg; carry[wave][k][1] = cx; carry[wave][k][2] = cD; }
+            const float dalpha = Tt * Dv;
             const float sg = t_sigmoid(rv[3]);                                 // softplus'
             float ga = dalpha * ea * dist * sg + cE * (1.f - sg);              // + d(-mean(a - softplus a))  MOD:263
             float gz[3] = {G0 * w * c0 * (1.f - c0) + cE * (1.f - 2.f * c0),   // + d(-mean(c - 2 softplus c)) MOD:278

@@ -402,7 +402,7 @@ def render_rays(p, ray_batch: Tensor, cfg: OracleCfg, eps_alpha, eps_rgb, is_tra
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]      # RUN:534
     raw, ent = run_network(p, pts, viewdirs, eps_alpha, eps_rgb, cfg, is_test=not is_train)   # RUN:537-538
     rgb_map, disp_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, white_bkgd)     # RUN:540
-    ret = dict(rgb_map=rgb_map, disp_map=disp_map, depth_map=depth_map, weights=weights, z_vals=z_vals)
+    ret = dict(rgb_map=rgb_map, disp_map=disp_map, depth_map=depth_map, weights=weights, z_vals=z_vals, rays_d=rays_d)     # (z_vals, rays_d: test conveniences)
     if is_train:
         ret.update(raw=raw, loss_entropy=ent, pts=pts)                      # RUN:544-547
     return ret

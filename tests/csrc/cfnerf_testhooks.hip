@@ -61,6 +61,8 @@ CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, in
     else if (n == "enc") { src = q.enc; cnt = P * 64; }
     else if (n == "at") { src = q.at; cnt = q.n_tiles * kTileM * q.K * 2; }        // tile-transposed [tiles,K,64,2]: (e, T)
     else if (n == "raw") { src = q.raw; cnt = q.n_tiles * kTileM * q.K * 4; }      // tile-transposed [tiles,K,64,4]
+    else if (n == "z") { src = q.z; cnt = P; }                                     // z_vals [P]
+    else if (n == "rays") { src = q.rays; cnt = q.N * 11; }
     else return -1;
     if (cnt > max_floats) return -cnt;
     if (hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) return -1;

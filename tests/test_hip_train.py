@@ -963,12 +963,15 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
           entry and of its RMS, capped at G_CAP_OTHER (G_CAP on the density path) - no sum|c| allowance, no conditioning term;
       (d) coverage, one ray at a time (first / last ray, both sides of the 4-ray workgroup and 64-ray boundaries, the middle, random
           ones): a one-hot cotangent against the fp64 oracle on that ray alone.  Colour branch (views / h_rgb / flows_rgb / rgb base):
-          max(G_FLOOR, 8 x fp32 noise), cap G_CAP_OTHER.  On the density path a single ray's gradient is the difference of nearly equal
-          transmittance terms (measured at K = 2: HIP up to 4.4e-2 where the fp32 CPU oracle is at 8e-3, typically 1e-4 .. 3e-3 against
-          1e-5 .. 2e-3; either may be the worse one; 20 x apart in the worst case): a flat 0.1 there - this part of the test is a COVERAGE
-          check, a dropped or doubled k-part or tile of the ray is an error of >= 0.25 - and the fixed G_CAP_OTHER on the trunk, which
+          max(G_FLOOR, 8 x fp32 noise), cap G_CAP_OTHER.  Density path (alpha_mean / alpha_std / flows_alpha.* / h_alpha_linear.*): the SAME rule
+          since round 6 (util_hip.density_path_tol: 8 x the noise of the tensor on this ray - the fp32 CPU oracle's own error, the measured
+          conditioning of the forward point, a quarter of the path's worst - capped at the coverage bound; rounds 4 - 5 held it to a flat 0.1).  A single ray's density gradient is a difference of nearly equal transmittance terms; the kernels of rounds 1 - 5 formed it
+          as g T - suffix / x from the forward's T, whose wave product scan gives every sample its own rounding history, and sat 10 - 35 x
+          further from fp64 than torch's fp32 autograd on rays of several chunks (1e-4 where torch is at 3e-6 .. 9e-6).  The adjoint now carries
+          the cancelled quantity itself (comp_adjoint_D, csrc/cfnerf_device.h; bisected with tests/tools/density_bisect.py,
+          profiles/r06_density_bisect.txt) and is at the fp32 oracle's level on every ray measured.  The fixed G_CAP_OTHER on the trunk, which
           carries both branches (measured <= 4.3e-5)."""
-    from util_hip import G_CAP_OTHER, G_FLOOR, fuzz_case
+    from util_hip import G_CAP_OTHER, G_FLOOR, density_path_tol, fuzz_case, one_ray_conditioning
     seed, force = K2_DRAWS[name]
     c = fuzz_case(seed, **force)
     net, p, cfg = c["net"], c["p"], c["cfg"]
@@ -992,19 +995,28 @@ def test_k2_many_ray_draws_backward_isolated_from_the_loss_steepness(name):
         with O.relu_override(masks=m_i):
             ri = O.render_rays(qi, d(c["packed"][i:i + 1]), cfg, d(c["ea"]), d(c["er"]), True, d(tr_i), c["lindisp"], c["wb"], t_vals=d(c["t_vals"]))
             rj = O.render_rays(qj, c["packed"][i:i + 1], cfg, c["ea"], c["er"], True, tr_i, c["lindisp"], c["wb"], t_vals=c["t_vals"])
-        (ri["rgb_map"] * d(Gi)[None]).sum().backward()
+        (ri["rgb_map"] * d(Gi)[None]).sum().backward(retain_graph=True)          # (one_ray_conditioning walks the network's graph again)
         (rj["rgb_map"] * Gi[None]).sum().backward()
+        live = [k for k in keys if qi[k].grad is not None and float(qi[k].grad.abs().max()) > 0.0]
         for k in keys:
+            if k not in live:
+                off, cnt = net.layout[k]
+                assert not g_hip[off:off + cnt].any(), (i, k)
+        n32 = {k: rel(qj[k].grad, qi[k].grad) for k in live}            # what the reference's own fp32 arithmetic loses on this ray, per tensor
+        cond = one_ray_conditioning(ri, qi, keys, Gi, c["wb"])          # ... and how far a 2e-7 move of the forward point moves each tensor
+        worst = ("", 0.0, 0.0)
+        for k in live:
             off, cnt = net.layout[k]
             gk = qi[k].grad
-            if gk is None or float(gk.abs().max()) == 0.0:
-                assert not g_hip[off:off + cnt].any(), (i, k)
-                continue
             e = rel(g_hip[off:off + cnt].reshape(gk.shape), gk)
             # the trunk (pts_linears) feeds h_alpha_linear as well as the colour branch: it carries the density path's one-ray noise too
-            n32 = rel(qj[k].grad, gk)
-            tol = (0.1 if "alpha" in k else G_CAP_OTHER if k.startswith("pts_linears") else min(max(G_FLOOR, 8 * n32), G_CAP_OTHER))
-            assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e} (fp32 CPU oracle on this ray: {n32:.1e})"
+            tol = (density_path_tol(n32, cond, k) if "alpha" in k else G_CAP_OTHER if k.startswith("pts_linears") else min(max(G_FLOOR, 8 * n32[k]), G_CAP_OTHER))
+            assert e <= tol, f"ray {i}, {k}: {e:.2e} of the largest entry exceeds {tol:.1e} (fp32 CPU oracle on this ray: {n32[k]:.1e})"
+            if "alpha" in k and e / tol > worst[1]:
+                worst = (k, e / tol, e)
+        n_path = max(v for k, v in n32.items() if "alpha" in k)
+        print(f"{name} ray {i}: density path worst {worst[0]} at {worst[2]:.1e} = {worst[1]:.2f} of its bound (fp32 CPU oracle: {n32[worst[0]]:.1e} on that tensor, {n_path:.1e} worst on "
+              f"the path; conditioning {cond.get(worst[0], 0.0):.1e})")
 
 
 def test_one_hot_cotangent_reaches_every_ray_at_production_batch():

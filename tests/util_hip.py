@@ -235,6 +235,47 @@ G_ALPHA_X = 2.0            # the density ("alpha") path is the ill-conditioned o
 G_CAP_OTHER = 2e-4         # every tensor OUTSIDE the alpha path: the calibration can only tighten the fixed bound of round 2, never loosen it
 
 
+ONE_RAY_COVERAGE = 0.1     # a one-ray gradient that lost or doubled a k-part / a tile of the ray is off by >= 0.25 of its largest entry
+
+
+def one_ray_conditioning(ret64, q64, keys, Gi, white_bkgd, draws=3, rel_step=2e-7, seed=0):
+    """{tensor: c}: how far the fp64 one-ray gradient of sum(Gi * rgb_map) moves (of its largest entry; the largest of `draws` draws) when
+    the forward's flow outputs `raw` move by rel_step of their magnitude - what two correct fp32 forwards differ by (measured: HIP raw against the
+    fp64 chain 1.3e-7 .. 2.6e-7).  ret64 / q64: the fp64 oracle's render_rays of that ray (graph alive) and its parameter leaves."""
+    raw, z = ret64["raw"], ret64["z_vals"].detach()
+    gen = torch.Generator().manual_seed(seed)
+
+    def params_grad(raw_at):
+        x = raw_at.detach().clone().requires_grad_(True)
+        o = O.raw2outputs(x, z, ret64["rays_d"], white_bkgd)
+        (gx,) = torch.autograd.grad((o[0] * Gi.to(x.dtype)[None]).sum(), x)
+        return dict(zip(keys, torch.autograd.grad(raw, [q64[k] for k in keys], gx, retain_graph=True, allow_unused=True)))
+    g0 = params_grad(raw)
+    out = {k: 0.0 for k in keys if g0[k] is not None and float(g0[k].abs().max()) > 0.0}
+    for _ in range(draws):
+        u = torch.rand(raw.shape, generator=gen, dtype=raw.dtype) * 2 - 1
+        g1 = params_grad(raw.detach() * (1.0 + rel_step * u))
+        for k in out:
+            out[k] = max(out[k], float((g1[k] - g0[k]).abs().max() / g0[k].abs().max()))
+    return out
+
+
+def density_path_tol(n32, cond, key, floor=G_FLOOR):
+    """Bound of ONE density-path tensor of a ONE-ray gradient (of the tensor's largest entry): max(floor, 8 x noise) - the colour branch's
+    rule - capped at the coverage bound, with the noise of this tensor ON THIS RAY read robustly:
+      n32[key]   what the SAME one-ray differentiation in fp32 on the CPU (the reference's arithmetic) loses against fp64,
+      cond[key]  the conditioning: how far a 2e-7 move of the forward's `raw` moves this tensor in fp64 (one_ray_conditioning),
+      a quarter of the worst n32 on the density path.
+    Why three readings: the density tensors of a ray are all linear images of ONE vector, d loss / d raw[..., 3] per (sample, latent), whose
+    entries carry the fp32 forward's conditioning (alpha = 1 - e of a nearly transparent sample keeps 3 digits: the kernel's formula
+    evaluated in fp64 at its fp32 inputs is 1e-4 .. 5e-4 per entry from the exact answer, like the fp32 oracle and like the kernel -
+    tests/tools/density_bisect.py, profiles/r06_density_bisect.txt).  How much of it survives in a tensor is ONE draw of a cancelling sum,
+    and the ratio of two such draws (kernel / fp32 oracle) is heavy-tailed: the oracle's draw is now and then 20 - 50 x luckier on one
+    tensor than on its neighbours (measured: alpha_mean 1.3e-6 next to alpha_std 1.8e-4)."""
+    n_path = max(v for k, v in n32.items() if "alpha" in k)
+    return min(max(floor, 8.0 * max(n32[key], cond.get(key, 0.0), 0.25 * n_path)), ONE_RAY_COVERAGE)
+
+
 def grad_close_tight(g, ref, what, tol=None):
     """Every entry of a gradient tensor within `tol` of the tensor's largest entry (+ 1e-4 relative), and the tensor's RMS error
     within `tol` of its RMS.  `ref`: numpy, or a torch tensor from oracle_train_step_on_hip_masks - those carry `fp32_noise`, the
