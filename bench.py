@@ -49,6 +49,9 @@ CONFIGS = {
                                                                                "no NDC), rows tiled across ranks, fused K-statistics (uncertainty maps)"),
     "W512": dict(n=512, K=32, W=512, ha=64, mode="train", scene="fern", what="the authors' recipe (train_NF.sh): W=512, h_alpha=64, K=32, N_rand=512"),
     "K64": dict(n=1024, K=64, W=256, ha=32, mode="train", scene="fern", what="LLFF-fern-shaped NDC rays at the reference's default K_samples=64 (RUN:631)"),
+    "N8192": dict(n=8192, K=4, W=256, ha=32, mode="train", scene="fern", max_rays=1024,
+                  what="C2's rays, 8192 per optimiser step walked in 8 slices of 1024 (Trainer(max_rays_per_launch=1024), cfnerf_render_bwd_accumulate): "
+                       "the workspace of a 1024-ray step"),
 }
 
 
@@ -192,7 +195,8 @@ class Workload:
         if self.mode == "train":
             from cfnerf_amd import train as T
             self.trainer = T.Trainer(self.net, lrate=5e-4, lrate_decay=250, beta1=0.01, world_size=world, force_allreduce=force_dist,
-                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "0") == "1", time_comm=world > 1 or force_dist)
+                                     overlap_comm=os.environ.get("CFNERF_BENCH_OVERLAP", "0") == "1", time_comm=world > 1 or force_dist,
+                                     max_rays_per_launch=cfg.get("max_rays"))
         self.hier = hierarchical
 
     def step(self):
@@ -232,8 +236,11 @@ class Workload:
         return (f"{self.name}: {c['what']}; {n}, S={S} (reference table, single pass), K={self.K}, W={self.W}, D={D}, h_alpha={c['ha']}, "
                 f"mode={self.mode}, precision={precision}")
 
+    def launches_per_step(self):
+        return -(-self.n // (self.cfg.get("max_rays") or self.n))
+
     def fwd_flops(self):
-        return gemm_flops_per_point(self.W, self.cfg["ha"]) * self.n * S
+        return gemm_flops_per_point(self.W, self.cfg["ha"]) * min(self.n, self.cfg.get("max_rays") or self.n) * S       # per LAUNCH (a slice of the step)
 
 
 def timed(wl, steps, warmup, sync, per_step=None):
@@ -833,7 +840,7 @@ def main():
             out["config"]["parallelism"] += " [CFNERF_BENCH_SAME_GPU=1: all ranks share cuda:0 and exchange over gloo - a code-path test, not a scaling number]"
         if mode == "train":
             out["kernel_ms"] = kms
-            out["step_frac_of_peak"] = 3 * fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF
+            out["step_frac_of_peak"] = 3 * fl * wl.launches_per_step() / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF
         if psnr is not None:
             out["psnr"] = psnr
         if evalb is not None:

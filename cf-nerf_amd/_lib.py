@@ -42,6 +42,7 @@ _SIGS = {
     "cfnerf_model_set_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "cfnerf_model_stash_generation": (C.c_uint64, [_P]),
     "cfnerf_render_bwd": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "cfnerf_render_bwd_accumulate": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     "cfnerf_network_bwd": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P]),
     "cfnerf_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "cfnerf_grad_early_ranges": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),

@@ -1062,8 +1062,9 @@ void dw_small_kernel(const DwTile* __restrict__ tiles, const DwBlock* __restrict
 // grad[i] = sum over the split slots that the tensor containing i actually uses (segments sorted by offset)
 // phase 1: only the tensors whose tiles all belong to the big launches (final before the small-job launch); phase 0: the rest;
 // phase 2: every tensor in one launch (the caller never asked for the early ranges: nothing waits between the two)
+// accumulate (cfnerf_render_bwd_accumulate): the sums are ADDED to grad instead of stored (a batch walked in slices)
 __global__ void reduce_weights_kernel(const float* __restrict__ partials, const RedSeg* __restrict__ segs, int n_segs, int64_t n_params,
-                                      float* __restrict__ grad, int phase) {
+                                      float* __restrict__ grad, int phase, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_params) return;
     int lo = 0, hi = n_segs - 1;
@@ -1083,12 +1084,13 @@ __global__ void reduce_weights_kernel(const float* __restrict__ partials, const 
         s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
     }
     for (; k < ns; ++k) s0 += q[(size_t)k * n_params];
-    grad[i] = (s0 + s1) + (s2 + s3);
+    const float r = (s0 + s1) + (s2 + s3);
+    grad[i] = accumulate ? grad[i] + r : r;
 }
 
 __global__ __launch_bounds__(1024)
 void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const BiasMap* __restrict__ maps, int n_maps,
-                        float* __restrict__ grad) {
+                        float* __restrict__ grad, int accumulate) {
     __shared__ float sh[16][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;       // 16 row groups x 64 columns
     const int j = blockIdx.x * 64 + lane;                             // column of the bias partial table
@@ -1108,13 +1110,16 @@ void reduce_bias_kernel(const float* __restrict__ dbp, int n_wg, int nb, const B
 #pragma unroll
         for (int q = 0; q < 16; ++q) tot += sh[q][lane];
         for (int q = 0; q < n_maps; ++q)
-            if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) grad[maps[q].dst + (j - maps[q].col0)] = tot;
+            if (j >= maps[q].col0 && j < maps[q].col0 + maps[q].count) {
+                float* g = grad + maps[q].dst + (j - maps[q].col0);
+                *g = accumulate ? *g + tot : tot;
+            }
     }
 }
 
 // base-Gaussian parameters: chain through z0 = eps*std + mean (tail partials) + d mean(base log-normal)/d std = -1/std
 __global__ void reduce_gms_kernel(const float* __restrict__ gms, int64_t n_rows, const float* __restrict__ flat,
-                                  const float* __restrict__ d_ent, float* __restrict__ grad) {
+                                  const float* __restrict__ d_ent, float* __restrict__ grad, int accumulate) {
     __shared__ double sh[8][256];
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = threadIdx.x; r < n_rows; r += blockDim.x)
@@ -1127,12 +1132,14 @@ __global__ void reduce_gms_kernel(const float* __restrict__ gms, int64_t n_rows,
     }
     if (threadIdx.x == 0) {
         const float ge = d_ent ? d_ent[0] : 0.f;
-        grad[0] = (float)sh[0][0];                                       // alpha_mean
-        grad[1] = (float)sh[1][0] + ge * (-1.f / flat[1]);               // alpha_std: + d mean(base_a)/d std
+        float r[8];
+        r[0] = (float)sh[0][0];                                          // alpha_mean
+        r[1] = (float)sh[1][0] + ge * (-1.f / flat[1]);                  // alpha_std: + d mean(base_a)/d std
         for (int c = 0; c < 3; ++c) {
-            grad[2 + c] = (float)sh[2 + c][0];                           // rgb_mean
-            grad[5 + c] = (float)sh[5 + c][0] + ge * (-1.f / (3.f * flat[5 + c]));   // rgb_std (mean over 3 channels, MOD:283,286)
+            r[2 + c] = (float)sh[2 + c][0];                              // rgb_mean
+            r[5 + c] = (float)sh[5 + c][0] + ge * (-1.f / (3.f * flat[5 + c]));      // rgb_std (mean over 3 channels, MOD:283,286)
         }
+        for (int i = 0; i < 8; ++i) grad[i] = accumulate ? grad[i] + r[i] : r[i];
     }
 }
 
@@ -1303,7 +1310,7 @@ int cfnerf_loss_fwd_bwd(const float* rgb_map, const float* target, const float* 
 // Backward of the stashed forward, shared by the fused (cfnerf_render_bwd: rays, `d_out` = d_rgb_map) and the unfused
 // (cfnerf_network_bwd: points, `d_out` = d_raw) entry points: first stage -> g_theta, then backward-data and the weight gradients.
 static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generation, const float* d_out, const float* d_depth_map,
-                            const float* d_entropy, float* grad_flat, cfnerf_stream s) {
+                            const float* d_entropy, float* grad_flat, int accumulate, cfnerf_stream s) {
     Stash& q = m->stash;
     if (!q.valid) return bfail(CFNERF_E_INVALID, "no stashed forward: call cfnerf_render_fwd / cfnerf_network_fwd with CFNERF_F_STASH first");
     if (stash_generation != q.generation)
@@ -1366,7 +1373,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         BHIP(launch_flows_bwd(q.raw, q.theta, m->d_eps, m->flat, d_out, d_entropy, P, q.K, q.g_theta, q.gms, &grid, st));
         gms_rows = (int64_t)grid * kWaves;                       // one row per wave (waves past P contribute zeros)
     }
-    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, gms_rows, m->flat, d_entropy, grad_flat);
+    hipLaunchKernelGGL(reduce_gms_kernel, dim3(1), dim3(256), 0, st, q.gms, gms_rows, m->flat, d_entropy, grad_flat, accumulate);
     BHIP(hipGetLastError());
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[1], st));
 
@@ -1382,7 +1389,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
     BHIP(launch_bwd_data(ba, m->plan.tab, m->precision, st, &grid_bd));
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[2], st));
     hipLaunchKernelGGL(reduce_bias_kernel, dim3((unsigned)((B.nb + 63) / 64)), dim3(1024), 0, st, q.dbp, grid_bd, B.nb,
-                       q.bias_maps, (int)B.bias_maps.size(), grad_flat);
+                       q.bias_maps, (int)B.bias_maps.size(), grad_flat, accumulate);
     BHIP(hipGetLastError());
 
     // ---- 3. weight gradients + reductions
@@ -1403,7 +1410,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
     const unsigned red_grid = (unsigned)((n_params + 255) / 256);
     if (!B.ev_early) BHIP(hipEventCreateWithFlags(&B.ev_early, hipEventDisableTiming));
     if (B.early_wanted) {
-        hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 1);
+        hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat, 1, accumulate);
         BHIP(hipGetLastError());
         BHIP(hipEventRecord(B.ev_early, st));
     }
@@ -1413,7 +1420,7 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
         BHIP(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_weights_kernel, dim3(red_grid), dim3(256), 0, st, q.partials, q.segs, (int)Hc.segs.size(), n_params, grad_flat,
-                       B.early_wanted ? 0 : 2);
+                       B.early_wanted ? 0 : 2, accumulate);
     BHIP(hipGetLastError());
     if (!B.early_wanted) BHIP(hipEventRecord(B.ev_early, st));      // (a waiter on the event still sees final gradients: everything is final here)
     if (m->timing == 1) BHIP(hipEventRecord(m->ev1[3], st));
@@ -1423,14 +1430,20 @@ static int backward_stashed(cfnerf_model* m, bool points, uint64_t stash_generat
 int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
                       const float* d_entropy, float* grad_flat, cfnerf_stream s) {
     if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
-    return backward_stashed(m, false, stash_generation, d_rgb_map, d_depth_map, d_entropy, grad_flat, s);
+    return backward_stashed(m, false, stash_generation, d_rgb_map, d_depth_map, d_entropy, grad_flat, 0, s);
+}
+
+int cfnerf_render_bwd_accumulate(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+                                 const float* d_entropy, float* grad_flat, cfnerf_stream s) {
+    if (!m || !d_rgb_map || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
+    return backward_stashed(m, false, stash_generation, d_rgb_map, d_depth_map, d_entropy, grad_flat, 1, s);
 }
 
 int cfnerf_network_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_raw, const float* d_entropy, float* grad_flat,
                        cfnerf_stream s) {
     if (!m || !grad_flat) return bfail(CFNERF_E_INVALID, "NULL argument");
     if (!d_raw && !d_entropy) return bfail(CFNERF_E_INVALID, "d_raw and d_entropy are both NULL: nothing to differentiate");
-    return backward_stashed(m, true, stash_generation, d_raw, nullptr, d_entropy, grad_flat, s);
+    return backward_stashed(m, true, stash_generation, d_raw, nullptr, d_entropy, grad_flat, 0, s);
 }
 
 int cfnerf_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int64_t N, int S, int K, int white_bkgd,

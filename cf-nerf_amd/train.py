@@ -68,7 +68,11 @@ class Trainer:
     identical seeding; step 0 uses one broadcast.  An explicit ``eps=`` argument overrides this (tests, benchmarks)."""
 
     def __init__(self, net, lrate=5e-4, lrate_decay=250, beta1=0.0, world_size=1, group=None, start=0, force_allreduce=False,
-                 overlap_comm=False, time_comm=False):
+                 overlap_comm=False, time_comm=False, max_rays_per_launch=None):
+        # max_rays_per_launch: a step's shard larger than this is walked in EQUAL slices (forward -> loss -> backward per slice, the
+        # gradient accumulated by cfnerf_render_bwd_accumulate, ONE exchange and ONE Adam step at the end): the train-step workspace
+        # is sized for a slice (3 MiB per ray at W = 256), not for the batch - the reference trains any N_rand (RUN:88-100,602)
+        self.max_rays = None if not max_rays_per_launch else int(max_rays_per_launch)
         self.force_allreduce = bool(force_allreduce)
         self.overlap_comm = bool(overlap_comm)
         # time_comm: two events on the compute stream around every gradient exchange - what the exchange EXPOSES on that stream
@@ -234,18 +238,59 @@ class Trainer:
             eps = net.draw_eps()
         eps = _f32c(eps)
         net._sync()
-        net.ensure_workspace(N, S, K)
         flags = L.F_STASH | L.F_TRAIN | (L.F_LINDISP if lindisp else 0) | (L.F_WHITE_BKGD if white_bkgd else 0)
-        L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(_f32c(t_rand) if t_rand is not None else None),
-                                      None, L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
-                                      None, None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
-        L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(_f32c(target)), L.ptr(self.entropy), N, K,
-                                        C.c_float(self.beta1 / self.world), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
-                "cfnerf_loss_fwd_bwd")
-        gen = lib.cfnerf_model_stash_generation(net.handle)
-        L.check(lib.cfnerf_render_bwd(net.handle, gen, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
-                                      L.ptr(self.grad), st), "cfnerf_render_bwd")
+        n_sl = self.n_slices(N)
+        t_rand = _f32c(t_rand) if t_rand is not None else None
+        target = _f32c(target)
+        if n_sl == 1:
+            net.ensure_workspace(N, S, K)
+            L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed), L.ptr(t_vals), L.ptr(t_rand),
+                                          None, L.ptr(eps), N, S, K, flags, L.ptr(self.rgb_map), L.ptr(self.disp), L.ptr(self.depth),
+                                          None, None, None, None, L.ptr(self.entropy), st), "cfnerf_render_fwd")
+            L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map), L.ptr(target), L.ptr(self.entropy), N, K,
+                                            C.c_float(self.beta1 / self.world), N * self.world, L.ptr(self.d_rgb), L.ptr(self.scalars), st),
+                    "cfnerf_loss_fwd_bwd")
+            gen = lib.cfnerf_model_stash_generation(net.handle)
+            L.check(lib.cfnerf_render_bwd(net.handle, gen, L.ptr(self.d_rgb), None, L.ptr(self.d_ent) if self.beta1 else None,
+                                          L.ptr(self.grad), st), "cfnerf_render_bwd")
+            return self.grad
+        # ---- the shard in n_sl equal slices: every loss term is taken with n_total = the FULL batch and beta1 / (world n_sl) on the slice's
+        # entropy (equal slices: the mean of the slice means is the batch mean), so the slice gradients and the scalar contributions ADD
+        Ns = N // n_sl
+        net.ensure_workspace(Ns, S, K)
+        if getattr(self, "_sl_n", None) != n_sl:
+            dev = net.flat.device
+            self._d_ent_sl = torch.tensor([self.beta1 / (self.world * n_sl)], device=dev)
+            self._sc_sl, self._ent_sl = torch.zeros(4, device=dev), torch.zeros(1, device=dev)
+            self._sl_n = n_sl
+        beta_sl = C.c_float(self.beta1 / (self.world * n_sl))
+        sc_sum, ent_sum = torch.zeros(4, device=net.flat.device), torch.zeros(1, device=net.flat.device)
+        for i in range(n_sl):
+            a, b = i * Ns, (i + 1) * Ns
+            L.check(lib.cfnerf_render_fwd(net.handle, L.ptr(self.packed[a:b]), L.ptr(t_vals), L.ptr(t_rand[a:b]) if t_rand is not None else None,
+                                          None, L.ptr(eps), Ns, S, K, flags, L.ptr(self.rgb_map[a:b]), L.ptr(self.disp[a:b]), L.ptr(self.depth[a:b]),
+                                          None, None, None, None, L.ptr(self._ent_sl), st), "cfnerf_render_fwd")
+            L.check(lib.cfnerf_loss_fwd_bwd(L.ptr(self.rgb_map[a:b]), L.ptr(target[a:b]), L.ptr(self._ent_sl), Ns, K, beta_sl, N * self.world,
+                                            L.ptr(self.d_rgb[a:b]), L.ptr(self._sc_sl), st), "cfnerf_loss_fwd_bwd")
+            gen = lib.cfnerf_model_stash_generation(net.handle)
+            bwd = lib.cfnerf_render_bwd if i == 0 else lib.cfnerf_render_bwd_accumulate
+            L.check(bwd(net.handle, gen, L.ptr(self.d_rgb[a:b]), None, L.ptr(self._d_ent_sl) if self.beta1 else None, L.ptr(self.grad), st),
+                    "cfnerf_render_bwd" if i == 0 else "cfnerf_render_bwd_accumulate")
+            sc_sum += self._sc_sl
+            ent_sum += self._ent_sl
+        self.scalars[:3] = sc_sum[:3]
+        self.scalars[3] = -10.0 * torch.log10(sc_sum[2])                # HLP:16 on the batch's mse
+        self.entropy.copy_(ent_sum / n_sl)
         return self.grad
+
+    def n_slices(self, N):
+        """Slices a shard of N rays is walked in: the fewest EQUAL ones of at most max_rays_per_launch rays (1 without a limit)."""
+        if not self.max_rays or N <= self.max_rays:
+            return 1
+        n = -(-N // self.max_rays)
+        while N % n:
+            n += 1
+        return n
 
     def step(self, H, W, focal, rays, target, **kw):
         """One full train step.  Returns the device tensor [loss, loss_nll, mse, psnr] of the local shard."""

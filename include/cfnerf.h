@@ -209,6 +209,16 @@ CFNERF_API uint64_t cfnerf_model_stash_generation(const cfnerf_model* m);
  * means 0.  grad_flat [param_count] is OVERWRITTEN with the gradient in the flat parameter layout.             */
 CFNERF_API int cfnerf_render_bwd(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
                       const float* d_entropy, float* grad_flat, cfnerf_stream s);
+/* replaces: the same loss.backward() when ONE optimiser step's batch is walked in slices (the reference renders any N_rand and any
+ * `chunk`, RUN:88-100,602: its autograd graph grows with the batch; here the train-step workspace does - 3 MiB per ray at W = 256 -
+ * so a batch larger than the workspace the caller wants to lend is cut into equal slices, each rendered with CFNERF_F_STASH and
+ * differentiated before the next one replaces the stash).  Exactly cfnerf_render_bwd, except that the slice's gradient is ADDED to
+ * grad_flat: call cfnerf_render_bwd for the first slice (it overwrites) and this for the others, with the loss of every slice taken
+ * with n_total = the FULL batch (cfnerf_loss_fwd_bwd) and d_entropy = beta1 / n_slices.  The sum over slices is the full batch's
+ * gradient up to the summation order (tests/test_hip_train.py: 8 x 1024 rays against one 8192-ray launch).  The early ranges
+ * (cfnerf_grad_early_ranges) are final only after the LAST slice's call.                                                           */
+CFNERF_API int cfnerf_render_bwd_accumulate(cfnerf_model* m, uint64_t stash_generation, const float* d_rgb_map, const float* d_depth_map,
+                                 const float* d_entropy, float* grad_flat, cfnerf_stream s);
 
 /* ---- the UNFUSED seam, differentiable like the reference's ---------------------------------------------------------
  * In the reference NeRF_Flows.forward (MOD:188-291) and raw2outputs (RUN:411-454) are ordinary autograd graphs, so a caller

@@ -40,7 +40,7 @@ def _dynamic_symbols(path):
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
-    """The PRODUCT library is built with -fvisibility=hidden + a version script: `nm -D --defined-only` lists the 33 entry points of
+    """The PRODUCT library is built with -fvisibility=hidden + a version script: `nm -D --defined-only` lists the 34 entry points of
     include/cfnerf.h and NOTHING else - no C++ symbol, no internal helper, no test hook (round 3 exported 226 mangled names and seven
     undeclared C ones; round 4 still shipped the six cfnerf_debug_* hooks in it).  The hooks of tests/cfnerf_debug.h are the whole
     dynamic symbol table of the separate TEST library, which nothing under cf-nerf_amd/ refers to."""
@@ -48,7 +48,7 @@ def test_dynamic_symbol_table_is_exactly_the_header():
     exported = _dynamic_symbols(L.LIB_PATH)
     abi = _declared(os.path.join(ROOT, "include", "cfnerf.h"))
     declared_hooks = _declared(os.path.join(ROOT, "tests", "cfnerf_debug.h"))
-    assert len(abi) == 33 and len(declared_hooks) == 7 and not (abi & declared_hooks)
+    assert len(abi) == 34 and len(declared_hooks) == 7 and not (abi & declared_hooks)
     assert all(h.startswith("cfnerf_debug_") for h in declared_hooks), declared_hooks
     assert exported == abi, {"undeclared": sorted(exported - abi)[:10], "missing": sorted(abi - exported)}
     assert not any("debug" in e for e in exported)
@@ -418,3 +418,11 @@ def test_header_is_plain_c_and_the_c_consumer_builds():
         TC.write_case(case, g)
         r = subprocess.run([exe, case], capture_output=True, text=True)
     assert r.returncode == 2 and "device" in r.stderr.lower(), (r.returncode, r.stderr)
+
+
+def test_trainer_slice_counts():
+    """Trainer(max_rays_per_launch=): a shard is walked in the FEWEST EQUAL slices of at most that many rays (cf-nerf_amd/train.py)"""
+    import types
+    from cfnerf_amd import train as TR
+    f = lambda N, mx: TR.Trainer.n_slices(types.SimpleNamespace(max_rays=mx), N)
+    assert f(8192, 1024) == 8 and f(1024, 1024) == 1 and f(1000, None) == 1 and f(200, 64) == 4 and f(7, 2) == 7 and f(4096, 1000) == 8
