@@ -52,6 +52,8 @@ struct DwTile {
     int32_t lay;                                          // operand layouts: bit 0 = dY, bit 1 = X is a Q4 stream (cfnerf_device.h), else row-major
     int32_t row_f;                                        // 0, or (theta-head tiles) the model's n_flows: dY column 4 b + f is destination row b F + f of
                                                           // the concatenated heads, columns with f >= n_flows are dropped (cfnerf_layout.h)
+    int32_t late;                                         // 1: which launch this job runs in depends on the stash LAYOUT (ONE Q4-capable operand: big row-major, small
+                                                          // with Q4) - its tensor is never reported as early, so the early ranges depend on the configuration only
 };
 
 struct BiasMap { int32_t col0, count; uint32_t dst; };

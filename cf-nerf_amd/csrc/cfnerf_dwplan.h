@@ -20,9 +20,15 @@ constexpr int kDwRows = 32;                   // points per LDS stage of both we
 // tiles of (32 GN) x (32 GK WK), GN GK = 8 waves, with the wave arrangement picked from the job's shape
 inline void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const float* dY, int ldY, int Nread, int N, const float* X,
                     int ldX, int K, int Kvalid, int nseg, const int* seg_row, const uint32_t* seg_dst, int dst_ld, int dst_col, int row_f = 0,
-                    int lay = 0) {
-    // (a job with ONE Q4 operand - g_ha x h or g_hr x v at head sizes of 128 - goes to the small kernel, which takes either layout per operand)
-    const bool is_big = N >= 128 && Kvalid >= 128 && (lay == 0 || lay == 3);
+                    int q4cap = 0, bool q4 = false) {
+    // q4cap: which operands are streams that take the Q4 layout when the stash does (bit 0 = dY, bit 1 = X); lay = what they ARE in this plan.
+    // (a job with ONE Q4 operand - g_ha x h at h_alpha_size 128 - goes to the small kernel, which takes either layout per operand: WHERE such
+    // a job runs depends on the stash layout, so its tensor must never count as "early" - the ranges of cfnerf_grad_early_ranges are cached by
+    // callers and have to depend on the configuration alone)
+    const int lay = q4 ? q4cap : 0;
+    const bool shape_big = N >= 128 && Kvalid >= 128;
+    const bool is_big = shape_big && (lay == 0 || lay == 3);
+    const bool late = shape_big && (q4cap == 1 || q4cap == 2);
     int gk = 0, wk = 0;
     if (!is_big) {          // wave arrangement GN x GK (GN GK = 8) from the job's K; a tile stages at most 128 + 64 or 64 + 128 columns
         wk = 1;
@@ -36,7 +42,7 @@ inline void add_job(std::vector<DwTile>& big, std::vector<DwTile>& small, const 
             t.dY = dY; t.ldY = ldY; t.N = N; t.Npad = Nread; t.X = X; t.ldX = ldX; t.K = Kvalid; t.Kpad = K; t.n0 = n0; t.k0 = k0;
             t.nseg = nseg;
             for (int q = 0; q < 4; ++q) { t.seg_row[q] = q < nseg ? seg_row[q] : 0x7fffffff; t.seg_dst[q] = q < nseg ? seg_dst[q] : 0; }
-            t.dst_ld = dst_ld; t.dst_col = dst_col; t.row_f = row_f; t.lay = lay;
+            t.dst_ld = dst_ld; t.dst_col = dst_col; t.row_f = row_f; t.lay = lay; t.late = late ? 1 : 0;
             (is_big ? big : small).push_back(t);
         }
 }
@@ -51,23 +57,24 @@ inline void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
     const int one_row[1] = {0};
     // operand layouts (DwTile::lay: bit 0 = dY, bit 1 = X): with whole tiles in fp32 mode (Stash::q4) the trunk streams h[l], g_h[l] and
     // g_feat are Q4 (cfnerf_device.h); feature / v / g_v, the encodings, the narrow heads and theta / g_theta stay row-major
-    const int qY = q.q4 ? 1 : 0, qX = q.q4 ? 2 : 0;
+    const int qY = 1, qX = 2;
+    const bool Q = q.q4;
     for (int l = 0; l < D; ++l) {
         std::snprintf(key, sizeof key, "pts_linears.%d.weight", l);
         const uint32_t dst[1] = {(uint32_t)L.off(key)};
         const float* dY = q.g_h + (size_t)l * P * W;
         if (l == 0) {
-            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0, 0, qY);
+            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic, 0, 0, qY, Q);
         } else if (l - 1 == skip) {
-            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0, 0, qY);
-            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic, 0, qY | qX);
+            add_job(big, small, dY, W, W, W, q.enc, 64, 64, ic, 1, one_row, dst, ic + W, 0, 0, qY, Q);
+            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, ic + W, ic, 0, qY | qX, Q);
         } else {
-            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0, 0, qY | qX);
+            add_job(big, small, dY, W, W, W, q.h + (size_t)(l - 1) * P * W, W, W, W, 1, one_row, dst, W, 0, 0, qY | qX, Q);
         }
     }
     const float* hlast = q.h + (size_t)(D - 1) * P * W;
-    { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0, 0, qX); }
-    { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0, 0, qY | qX); }
+    { const uint32_t dst[1] = {(uint32_t)L.off("h_alpha_linear.weight")}; add_job(big, small, q.g_ha, HA, HA, HA, hlast, W, W, W, 1, one_row, dst, W, 0, 0, qX, Q); }
+    { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0, 0, qY | qX, Q); }
     {
         const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
         add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
@@ -223,7 +230,8 @@ inline const char* build_dw_plan(const cfnerf_cfg& c, const ParamLayout& L, cons
             for (int g = 0; g < t.nseg; ++g)
                 for (RedSeg& r : Hs.segs)
                     if (r.begin == t.seg_dst[g]) {
-                        if (r.nsplit == 0) r.early = big ? 1 : 0; else if (!big) r.early = 0;
+                        const bool e = big && !t.late;     // (a layout-dependent job is never early: DwTile::late)
+                        if (r.nsplit == 0) r.early = e ? 1 : 0; else if (!e) r.early = 0;
                         r.nsplit = std::max(r.nsplit, t.nsplit); ns_max = std::max(ns_max, t.nsplit);
                     }
     };

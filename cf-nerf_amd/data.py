@@ -99,12 +99,41 @@ class RayPool:
         g = torch.Generator(device=dev).manual_seed(self._mix(self.seed or 0, self.epoch))
         return torch.randperm(M, device=dev, generator=g)
 
+    def _check_same_permutation(self, idx):
+        """sync="seed" draws the epoch's permutation on every rank with no exchange - and relies on every rank's generator being the same
+        algorithm on the same kind of device (torch's device-side randperm picks its launch geometry from the device: another CU count or
+        partition mode, or a host-resident pool on one rank, would give another stream and shards that overlap or miss rays silently).  Once
+        per epoch the ranks therefore compare a position-weighted checksum of the indices (two scalars, MAX all-reduce; nothing when no
+        process group exists) and a mismatch raises instead of training on."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        w = torch.arange(1, idx.numel() + 1, device=idx.device, dtype=torch.int64) % 65521
+        c = (idx * w).sum()                                                  # < 2^63 up to ~10^7 rays
+        t = torch.stack([c, -c])
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            t = host
+        elif not t.is_cuda and dist.get_backend(self.group) == "nccl":
+            stage = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(stage, op=dist.ReduceOp.MAX, group=self.group)
+            t = stage
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if int(t[0]) != -int(t[1]):
+            raise RuntimeError(f"RayPool(sync='seed'): the ranks drew DIFFERENT permutations for epoch {self.epoch} from seed {self.seed} "
+                               "(different devices or generator algorithms); use sync='broadcast'")
+
     def _permutation(self):
         M, dev = self.rays_rgb.shape[0], self.rays_rgb.device
         if self.world == 1 and self.seed is None:
             return torch.randperm(M, device=dev, generator=self.generator)
         if self.world == 1 or self.sync == "seed":
-            return self._seeded_permutation(M, dev)
+            idx = self._seeded_permutation(M, dev)
+            if self.world > 1:
+                self._check_same_permutation(idx)
+            return idx
         import torch.distributed as dist
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         if self.rank == 0:

@@ -33,9 +33,11 @@ CFNERF_API int cfnerf_debug_stash_q4(cfnerf_model* m);
 /* the weight-gradient tiles of a configuration at P points: 12 int32 per tile + 4 destination segments each */
 CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles);
 /* the blocks of that plan for a point count and CU count: 5 int64 per block {kind, tile, split, pb, pe}, per tile its split count,
- * per parameter tensor the slot count of the reduction */
-CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
-                                      int32_t* seg_nsplit, int max_segs);
+ * per parameter tensor the slot count of the reduction and (seg_early, may be NULL) whether every job that feeds it belongs to the big launch
+ * in EITHER stash layout.  q4: the layout of the wide streams the plan is made for (1 / 0 as the product decides it: fp32 mode and whole
+ * tiles - S % 64 == 0 in ray mode, P % 64 == 0 in points mode; -1 = the points-mode rule applied to P) */
+CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int q4, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
+                                      int32_t* seg_nsplit, int32_t* seg_early, int max_segs);
 
 #ifdef __cplusplus
 }

@@ -108,7 +108,7 @@ CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
             int32_t* o = tiles_out + 16 * n;
             o[0] = pass == 0; o[1] = t.n0; o[2] = t.k0; o[3] = t.N; o[4] = t.K; o[5] = t.gk; o[6] = t.wk; o[7] = t.nseg;
             for (int g = 0; g < 4; ++g) { o[8 + g] = t.seg_row[g]; segdst_out[4 * n + g] = t.seg_dst[g]; }
-            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = t.row_f; o[15] = 0;
+            o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = t.row_f; o[15] = t.late;
             ++n;
         }
     return n;
@@ -117,8 +117,8 @@ CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
 // the blocks of that plan for a given point count and CU count: 5 int64 per block {kind (0: 2 x 4, 1: 1 x 8, 2: small job), tile, split,
 // pb, pe}; tile indices refer to the order cfnerf_debug_dw_plan reports (big tiles, then small tiles); plus per tile its nsplit and, per
 // parameter tensor, the slot count of the reduction.
-CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
-                                      int32_t* seg_nsplit, int max_segs) {
+CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu, int q4, int64_t* blocks_out, int max_blocks, int32_t* tile_nsplit,
+                                      int32_t* seg_nsplit, int32_t* seg_early, int max_segs) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);
     Stash q;
@@ -126,7 +126,9 @@ CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu
     const size_t step = size_t(1) << 36;
     float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
-    q.q4 = P % kTileM == 0;                                // as the fp32 product does for whole tiles (cfnerf_abi.hip): the Q4 bodies and their split costs
+    // q4: the layout of the wide streams the plan is made for - 1 / 0 as the product decides it (cfnerf_abi.hip: fp32 mode and whole tiles,
+    // i.e. S % 64 == 0 in ray mode, P % 64 == 0 in points mode), -1 = the points-mode rule applied to P
+    q.q4 = q4 < 0 ? (P % kTileM == 0) : (q4 != 0);
     DwHost H;
     int n_wide = 0, ns_max = 0;
     const char* why = build_dw_plan(*cfg, L, q, P, n_cu, H, &n_wide, &ns_max);
@@ -147,7 +149,7 @@ CFNERF_API int cfnerf_debug_dw_blocks(const cfnerf_cfg* cfg, int64_t P, int n_cu
     int t = 0;
     for (const DwTile& x : H.tiles) tile_nsplit[t++] = x.nsplit * (x.gk == 1 ? -1 : 1);     // sign: wave arrangement
     for (const DwTile& x : H.tiles_small) tile_nsplit[t++] = x.nsplit;
-    for (size_t i = 0; i < H.segs.size(); ++i) seg_nsplit[i] = H.segs[i].nsplit;
+    for (size_t i = 0; i < H.segs.size(); ++i) { seg_nsplit[i] = H.segs[i].nsplit; if (seg_early) seg_early[i] = H.segs[i].early; }
     return n;
 }
 }  // extern "C"

@@ -18,7 +18,7 @@ def trainer_rank(rank, world, port, q, spec):
         from cfnerf_amd import train as TR
         from oracle import cfnerf_oracle as O
         from util_hip import build_model, fern_rays
-        cfg = O.OracleCfg(netwidth=spec["W"], K_samples=spec["K"])
+        cfg = O.OracleCfg(netwidth=spec["W"], K_samples=spec["K"], h_alpha_size=spec.get("ha", 32))
         import contextlib
         import io
         with contextlib.redirect_stdout(io.StringIO()):
@@ -33,6 +33,8 @@ def trainer_rank(rank, world, port, q, spec):
         torch.manual_seed(1000 + rank)                        # DIFFERENT seeds per rank: the latents must still agree
         eps_used, losses = [], []
         for step in range(spec["steps"]):
+            if step in spec.get("precision_at", {}):           # the arithmetic mode (and with it the stash layout) changes between steps
+                model.module.set_precision(spec["precision_at"][step])
             t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
             kw = dict(t_rand=t_rand[lo:hi].cuda())
             if spec.get("explicit_eps"):

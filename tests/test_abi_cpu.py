@@ -334,7 +334,8 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     lib = hooks.lib()
     fn = lib.cfnerf_debug_dw_blocks
     fn.restype = C.c_int
-    fn.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
+    fn.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                   C.POINTER(C.c_int32), C.c_int]
     lib.cfnerf_debug_dw_plan.restype = C.c_int
     lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
     cfg = L.Cfg(D, W, 10, 4, 32, 64, 4)
@@ -342,7 +343,7 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     blocks = (C.c_int64 * (5 * cap))()
     tile_ns = (C.c_int32 * 1024)()
     seg_ns = (C.c_int32 * 256)()
-    n = fn(C.byref(cfg), P, n_cu, blocks, cap, tile_ns, seg_ns, 256)
+    n = fn(C.byref(cfg), P, n_cu, -1, blocks, cap, tile_ns, seg_ns, None, 256)
     assert n > 0
     b = np.ctypeslib.as_array(blocks).reshape(cap, 5)[:n]
     tiles = (C.c_int32 * (16 * 1024))()
@@ -426,3 +427,41 @@ def test_trainer_slice_counts():
     from cfnerf_amd import train as TR
     f = lambda N, mx: TR.Trainer.n_slices(types.SimpleNamespace(max_rays=mx), N)
     assert f(8192, 1024) == 8 and f(1024, 1024) == 1 and f(1000, None) == 1 and f(200, 64) == 4 and f(7, 2) == 7 and f(4096, 1000) == 8
+
+
+@pytest.mark.parametrize("W,ha", [(256, 128), (256, 32), (128, 128), (512, 64), (384, 96)])
+def test_early_gradient_ranges_do_not_depend_on_the_stash_layout(W, ha):
+    """cfnerf_grad_early_ranges promises ranges that depend on the configuration only (callers cache them: Trainer._exchange_plan).  With
+    h_alpha_size = 128 the job g_ha x h has ONE Q4-capable operand: it is a big tile while the stash is row-major (bf16x3, ragged S) and a
+    small job with the Q4 layout (fp32, whole tiles) - round 5 reported h_alpha_linear.weight as early in one case and late in the other, and
+    a cached early bucket would have been exchanged before the small-job launch wrote that tensor.  Such a job is marked `late` in either
+    plan (DwTile::late, csrc/cfnerf_dwplan.h): the per-tensor early flags of the two layouts are identical."""
+    import hooks
+    lib = hooks.lib()
+    fn = lib.cfnerf_debug_dw_blocks
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                   C.POINTER(C.c_int32), C.c_int]
+    cfg = L.Cfg(8, W, 10, 4, ha, 64, 4)
+    layout, _ = cfnerf_amd.param_layout(cfg)
+    keys = list(layout)
+    flags = {}
+    for q4 in (0, 1):
+        blocks = (C.c_int64 * (5 * 20000))()
+        tile_ns, seg_ns, seg_early = (C.c_int32 * 1024)(), (C.c_int32 * 256)(), (C.c_int32 * 256)()
+        assert fn(C.byref(cfg), 131072, 256, q4, blocks, 20000, tile_ns, seg_ns, seg_early, 256) > 0
+        flags[q4] = {k: int(seg_early[i]) for i, k in enumerate(keys)}
+    assert flags[0] == flags[1], {k: (flags[0][k], flags[1][k]) for k in keys if flags[0][k] != flags[1][k]}
+    assert flags[0]["feature_linear.weight"] == 1 and flags[0]["pts_linears.1.weight"] == 1          # fed by the big launch alone
+    assert flags[0]["h_alpha_linear.weight"] == 0 and flags[0]["h_rgb_linear.weight"] == 0 and flags[0]["pts_linears.0.weight"] == 0
+
+
+def test_wide_buffer_stores_keep_the_hazard_free_form():
+    """gfx950 reads the data registers of a buffer_store_dwordx4 with an SGPR offset late, and LLVM's hazard recognizer covers only the form
+    with a literal-0 soffset (round 5: sparse, run-to-run different garbage in g_h).  The protection is the FORM of the emitted instruction, so
+    it is read back from the built code objects: tools/check_wide_stores.py fails on any 12 / 16-byte buffer store with another soffset."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wide_stores.py"), L.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert int(r.stdout.split()[0]) >= 100, r.stdout            # (the Q4 epilogues and stash_rows are in there: the pattern still matches)

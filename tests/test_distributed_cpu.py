@@ -215,3 +215,34 @@ def test_sharded_ray_pool_seed_form_needs_no_exchange():
         rays1, tgt1 = one.next_batch()
         union_t = np.concatenate([got[0][step][1], got[1][step][1]], 0)
         np.testing.assert_array_equal(union_t, tgt1.numpy()[:union_t.shape[0]])
+
+
+def _pool_mismatch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cfnerf_amd.data import RayPool
+    try:                                                   # the ranks DISAGREE about the seed: what another device kind / generator would look like
+        RayPool.from_rays_rgb(_pool_table(), _POOL_NRAND, rank=rank, world=world, sync="seed", seed=77 + rank)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_seed_form_notices_ranks_that_drew_different_permutations():
+    """sync="seed" exchanges nothing per step; once per epoch the ranks compare a checksum of the permutation they drew, so ranks whose
+    generators disagree (another device kind, a host-resident pool on one rank) fail loudly instead of training on overlapping shards."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pool_mismatch_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all("DIFFERENT permutations" in got[r] for r in range(world)), got

@@ -46,7 +46,7 @@ def _run_ranks(spec, world=2):
 
 
 def _single_process(spec, eps_per_step):
-    cfg = O.OracleCfg(netwidth=spec["W"], K_samples=spec["K"])
+    cfg = O.OracleCfg(netwidth=spec["W"], K_samples=spec["K"], h_alpha_size=spec.get("ha", 32))
     _, kw_train, _, model, p, _ = build_model(cfg, spec["seed"])
     rng = np.random.default_rng(spec["data_seed"])
     N = spec["N"]
@@ -55,6 +55,8 @@ def _single_process(spec, eps_per_step):
     tr = TR.Trainer(model, lrate=5e-4, lrate_decay=250, beta1=spec["beta1"])
     losses = []
     for step in range(spec["steps"]):
+        if step in spec.get("precision_at", {}):
+            model.module.set_precision(spec["precision_at"][step])
         t_rand = torch.tensor(rng.uniform(0, 1, (N, 128)), dtype=torch.float32)
         sc = tr.step(H, Wd, focal, rays.to(DEV), target.to(DEV), t_rand=t_rand.to(DEV), eps=torch.tensor(eps_per_step[step]).to(DEV))
         losses.append(sc[:2].cpu().numpy())
@@ -92,6 +94,22 @@ def test_rccl_exchange_path_on_one_rank_is_the_identity(overlap):
     a one-rank group, where a sum all-reduce changes nothing: the parameters after three steps equal those of the
     plain single-process run bit for bit, so every element went through exactly one bucket and came back in place."""
     spec = dict(W=64, K=4, N=64, seed=21, data_seed=5, beta1=0.01, steps=3, explicit_eps=True, backend="nccl", force=True, overlap=overlap)
+    got = _run_ranks(spec, world=1)
+    flat0, losses0, _ = got[0]
+    eps = [np.random.default_rng(7000 + s).standard_normal((spec["K"], 4)).astype(np.float32) for s in range(spec["steps"])]
+    flat_ref, losses_ref = _single_process(spec, eps)
+    assert np.array_equal(flat0, flat_ref)
+    np.testing.assert_allclose(losses0, losses_ref, rtol=0, atol=0)
+
+
+def test_two_bucket_exchange_survives_a_change_of_the_stash_layout():
+    """h_alpha_size = 128: the job g_ha x h runs in the big launch while the stash is row-major (bf16x3) and in the small-job launch with the
+    Q4 layout (fp32, whole tiles).  The Trainer caches the early ranges after its first backward; round 5 reported h_alpha_linear.weight as
+    early in one layout and late in the other, so a run that changed the precision between steps all-reduced a stale early bucket BEFORE the
+    small jobs wrote that tensor and copied it back over the right gradient.  Such a job is never early now (DwTile::late): the two-bucket
+    exchange on a one-rank RCCL group across fp32 -> bf16x3 -> fp32 equals the plain single-process run bit for bit."""
+    spec = dict(W=128, ha=128, K=4, N=64, seed=23, data_seed=6, beta1=0.01, steps=4, explicit_eps=True, backend="nccl", force=True, overlap=True,
+                precision_at={1: "bf16x3", 3: "fp32"})
     got = _run_ranks(spec, world=1)
     flat0, losses0, _ = got[0]
     eps = [np.random.default_rng(7000 + s).standard_normal((spec["K"], 4)).astype(np.float32) for s in range(spec["steps"])]

@@ -891,6 +891,12 @@ def test_random_configurations_forward_and_gradients_vs_oracle(seed):
         L.check(lib.cfnerf_render_bwd(net.handle, lib.cfnerf_model_stash_generation(net.handle), L.ptr(G_dev), None,
                                       L.ptr(tr.d_ent) if beta1 else None, L.ptr(g_iso), L.stream()), "cfnerf_render_bwd")
         check_all_grads(net, g_iso.cpu(), grads_iso, what + " [backward in isolation]")
+        # ... and the gradient the Trainer returned IS that backward fed the loss kernel's own d_rgb (its chaining of loss -> backward: buffer,
+        # scaling, d_entropy): the same call again reproduces it bit for bit
+        g_own = torch.empty(net.n_params, device=DEV)
+        L.check(lib.cfnerf_render_bwd(net.handle, lib.cfnerf_model_stash_generation(net.handle), L.ptr(tr.d_rgb), None,
+                                      L.ptr(tr.d_ent) if beta1 else None, L.ptr(g_own), L.stream()), "cfnerf_render_bwd")
+        assert torch.equal(g_own.cpu(), grad), "Trainer.forward_backward's gradient is not cfnerf_render_bwd(d_rgb of its loss kernel)"
     else:
         check_all_grads(net, grad, grads, what)
 
