@@ -179,6 +179,20 @@ def _shape_of(key: str, numel: int, cfg: L.Cfg):
 
 # --------------------------------------------------------------------------------------------
 @torch.no_grad()
+def flow_buffers(n_flows, device="cpu"):
+    """The registered buffers of the reference's two flow stacks (MOD:323-333, FLW:180-181), which its ``state_dict()`` carries next to
+    the parameters: key -> tensor.  Device-free host logic (a checkpoint this build writes holds exactly the reference's key set:
+    ``param_layout`` keys + these)."""
+    out = OrderedDict()
+    for name, z in (("flows_rgb", 3), ("flows_alpha", 1)):
+        out[f"{name}.flip_idx"] = torch.arange(z - 1, -1, -1, device=device).long()             # MOD:323
+        out[f"{name}.triu_mask"] = torch.triu(torch.ones(z, z, device=device), diagonal=1)[None, :, :, None]
+        out[f"{name}.diag_idx"] = torch.arange(0, z, device=device).long()
+        for k in range(n_flows):
+            out[f"{name}.flow_{k}.diag_idx"] = torch.arange(0, z, device=device).long()         # FLW:180-181
+    return out
+
+
 def reference_init(shapes, netdepth, K_samples=None):
     """Initial values exactly as ``NeRF_Flows.__init__`` produces them under the same ``torch.manual_seed``
     (MOD:38-67, 339-350).  Throw-away CPU ``nn.Linear``s are created in the reference's construction order, so torch's
@@ -291,14 +305,7 @@ class NeRF_Flows(nn.Module):
         self._replay_reference_init(draw_latents=False)
 
     def _buffers_ref(self):
-        out = OrderedDict()
-        for name, z in (("flows_rgb", 3), ("flows_alpha", 1)):
-            out[f"{name}.flip_idx"] = torch.arange(z - 1, -1, -1, device=self.device).long()       # MOD:323
-            out[f"{name}.triu_mask"] = torch.triu(torch.ones(z, z, device=self.device), diagonal=1)[None, :, :, None]
-            out[f"{name}.diag_idx"] = torch.arange(0, z, device=self.device).long()
-            for k in range(self.n_flows):
-                out[f"{name}.flow_{k}.diag_idx"] = torch.arange(0, z, device=self.device).long()   # FLW:180-181
-        return out
+        return flow_buffers(self.n_flows, self.device)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         for key in self.layout:

@@ -271,6 +271,14 @@ def t2n(d):
 
 
 def main():
+    argv = sys.argv[1:]
+    out_dir = HERE
+    if "--out" in argv:
+        i = argv.index("--out")
+        out_dir = argv[i + 1]
+        del argv[i:i + 2]
+        os.makedirs(out_dir, exist_ok=True)
+    only = set(argv)                         # optional: regenerate only the named fixtures
     R = import_reference()
     import run_nerf_helpers as HLP
     tmp = tempfile.mkdtemp(prefix="cfnerf_golden_")
@@ -766,16 +774,65 @@ def main():
     g21.update(rgb_map_eval=rgbs_e, depth_map_eval=depth_e)
     out["g21_train_authors_recipe_w512"] = g21
 
+
+    # ---------------- G22: a CHECKPOINT THE REFERENCE WROTE (RUN:1085-1100), to be loaded through its loader's rules (RUN:345-378):
+    #                  the real NeRF_Flows under nn.DataParallel, constructed by create_nerf under a seed, two iterations of the loop lines so
+    #                  that torch.optim.Adam carries state, then the reference's own torch.save of {global_step, network_fn_state_dict,
+    #                  optimizer_state_dict} -> tests/golden/g22_reference_ckpt.tar (a pickled dict of tensors: data), and what the reference
+    #                  renders from that model in eval mode ----------------
+    rng22 = np.random.default_rng(122)
+    cfg = O.OracleCfg(netwidth=64, netdepth=4, K_samples=3)
+    args = ref_args(cfg, tmp, K_samples=3)
+    torch.manual_seed(4321)
+    kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+    model = kw_train["network_fn"]
+    net = model.module
+    n = 16
+    rays, (H, W, focal) = fern_rays(rng22, n)
+    rays_t = torch.tensor(rays)
+    target = torch.tensor(rng22.uniform(0, 1, (n, 3)), dtype=torch.float32)
+    global_step = 0
+    for step in range(2):
+        t_rand = torch.tensor(rng22.uniform(0, 1, (n, 128)), dtype=torch.float32)
+        ea = torch.tensor(rng22.standard_normal((3, 1)), dtype=torch.float32)
+        er = torch.tensor(rng22.standard_normal((3, 3)), dtype=torch.float32)
+        with ExplicitRandom(t_rand=t_rand, normals=[ea, er]):
+            rgbs, disp, depth, extras = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., verbose=False, retraw=False, **kw_train)
+        loss = reference_kde_nll(rgbs, target, 3) + 0.01 * extras["loss_entropy"].mean()
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        global_step += 1
+    tar_tmp = os.path.join(tmp, "g22_reference_ckpt.tar")                                  # (the archive records its own base name: same name, same bytes)
+    torch.save({                                                                           # RUN:1095-1099, the N_importance == 0 branch
+        'global_step': global_step,
+        'network_fn_state_dict': kw_train['network_fn'].state_dict(),
+        'optimizer_state_dict': optimizer.state_dict(),
+    }, tar_tmp)
+    with open(tar_tmp, "rb") as f:
+        tar_bytes = f.read()
+    if not only or "g22_reference_ckpt" in only:
+        with open(os.path.join(out_dir, "g22_reference_ckpt.tar"), "wb") as f:
+            f.write(tar_bytes)
+    ea = torch.tensor(rng22.standard_normal((3, 1)), dtype=torch.float32)
+    er = torch.tensor(rng22.standard_normal((3, 3)), dtype=torch.float32)
+    net.sample_alpha, net.sample_rgb = ea.clone(), er.clone()                             # eval latents: plain attributes, not in the checkpoint (R9)
+    with torch.no_grad():
+        rgbs_e, disp_e, depth_e, _ = R.render(H, W, focal, chunk=8192, rays=rays_t, near=0., far=1., **kw_test)
+    sd = model.state_dict()
+    g22 = dict(netwidth=64, netdepth=4, K=3, H=H, W=W, focal=focal, rays=rays_t, global_step=global_step, sample_alpha=ea, sample_rgb=er,
+               rgb_map_eval=rgbs_e, disp_map_eval=disp_e, depth_map_eval=depth_e, state_dict_keys=np.array(list(sd.keys())),
+               optimizer_state_entries=len(optimizer.state_dict()["state"]),
+               tar_sha256=np.array(__import__("hashlib").sha256(tar_bytes).hexdigest()), tar_bytes=len(tar_bytes))
+    for k, v in sd.items():
+        f = v.detach().reshape(-1)
+        g22["numel." + k] = f.numel()
+        g22["head." + k] = f[:4].clone()
+        g22["sum." + k] = f.double().sum()
+    out["g22_reference_ckpt"] = g22
+
     import hashlib
     import json
-    argv = sys.argv[1:]
-    out_dir = HERE
-    if "--out" in argv:
-        i = argv.index("--out")
-        out_dir = argv[i + 1]
-        del argv[i:i + 2]
-        os.makedirs(out_dir, exist_ok=True)
-    only = set(argv)                         # optional: regenerate only the named fixtures
     man_path = os.path.join(out_dir, "MANIFEST.json")
     manifest = {}
     if only and os.path.exists(man_path):

@@ -102,3 +102,38 @@ def test_checkpoint_roundtrip_in_the_reference_format():
         m3 = kw3["network_fn"].module
         assert torch.equal(m3.view("pts_linears.0.weight").cpu(), p["pts_linears.0.weight"])
         assert torch.equal(m3.view("rgb_mean").cpu(), torch.zeros(3))           # kept its init value
+
+
+def test_checkpoint_written_by_the_reference_loads_and_renders():
+    """G22: the .tar the REFERENCE's own save lines wrote (RUN:1085-1100; tests/golden/g22_reference_ckpt.tar, made by
+    tests/golden/make_golden.py from the real nn.DataParallel(NeRF_Flows) after two iterations of its loop) goes through
+    create_nerf(ft_path=...) -> _maybe_reload (the loader's rules, RUN:345-378): training resumes at its global_step, every parameter is
+    the checkpoint's bit for bit, and the fused eval render from those weights equals what the reference rendered from them."""
+    import numpy as np
+    from conftest import GOLDEN
+    from util_hip import close
+    g = dict(np.load(os.path.join(GOLDEN, "g22_reference_ckpt.npz"), allow_pickle=False))
+    tar = os.path.join(GOLDEN, "g22_reference_ckpt.tar")
+    cfg = O.OracleCfg(netwidth=int(g["netwidth"]), netdepth=int(g["netdepth"]), K_samples=int(g["K"]))
+    args = make_args(cfg, ft_path=tar, no_reload=False)
+    kw_train, kw_test, start, _, _ = cfnerf_amd.create_nerf(args)
+    assert start == int(g["global_step"]) == 2
+    net = kw_train["network_fn"].module
+    ck = torch.load(tar, map_location="cpu", weights_only=True)["network_fn_state_dict"]
+    sd = kw_train["network_fn"].state_dict()
+    assert set(sd) == set(ck)
+    for k, v in ck.items():
+        assert torch.equal(sd[k].cpu().to(v.dtype), v), k
+    net.sample_alpha, net.sample_rgb = torch.tensor(g["sample_alpha"]), torch.tensor(g["sample_rgb"])
+    with torch.no_grad():
+        rgbs, disp, depth, _ = cfnerf_amd.render(int(g["H"]), int(g["W"]), float(g["focal"]), rays=torch.tensor(g["rays"]).cuda(), near=0., far=1., **kw_test)
+    close(rgbs, g["rgb_map_eval"], what="rgb_map_eval")
+    close(depth, g["depth_map_eval"], what="depth_map_eval")
+    # ... and a checkpoint this build writes from that model holds the same key LIST in the same order with the same tensors
+    with tempfile.TemporaryDirectory() as d:
+        out = cfnerf_amd.save_checkpoint(os.path.join(d, "000002_01.tar"), 2, kw_train["network_fn"])
+        mine = torch.load(out, map_location="cpu", weights_only=True)
+    assert list(mine) == ["global_step", "network_fn_state_dict", "optimizer_state_dict"] and mine["global_step"] == 2
+    assert set(mine["network_fn_state_dict"]) == set(ck)
+    for k, v in ck.items():
+        assert torch.equal(mine["network_fn_state_dict"][k].to(v.dtype), v), k

@@ -528,3 +528,96 @@ def test_committed_generator_reproduces_the_fixtures(tmp_path):
         assert sorted(new) == sorted(old), name
         for k in new:
             assert new[k].dtype == old[k].dtype and new[k].shape == old[k].shape and new[k].tobytes() == old[k].tobytes(), (name, k)
+
+
+def _g22_tar():
+    import os
+    from conftest import GOLDEN
+    return os.path.join(GOLDEN, "g22_reference_ckpt.tar")
+
+
+def test_checkpoint_written_by_the_reference(golden):
+    """G22 / SURVEY 8f-3: tests/golden/g22_reference_ckpt.tar is what the REFERENCE's own save lines (RUN:1085-1100) wrote for its real
+    nn.DataParallel(NeRF_Flows) after two iterations of its loop (a pickled dict of tensors: data).  The committed file is the one the
+    generator makes (sha256 recorded in the fixture, which the manifest covers); its dict has the reference's three entries, every
+    network key carries the `module.` prefix, and the key LIST - parameters in state_dict order plus the flow stacks' registered buffers -
+    is the one this build writes and reads (cfnerf_amd.api.param_layout + flow_buffers: device-free host logic).  The oracle renders
+    the reference's eval output from those weights."""
+    import hashlib
+    import cfnerf_amd
+    from cfnerf_amd import _lib as L
+    from cfnerf_amd import api
+    g = golden("g22_reference_ckpt")
+    with open(_g22_tar(), "rb") as f:
+        blob = f.read()
+    assert len(blob) == int(g["tar_bytes"]) and hashlib.sha256(blob).hexdigest() == str(g["tar_sha256"])
+    ck = torch.load(_g22_tar(), map_location="cpu", weights_only=True)
+    assert list(ck) == ["global_step", "network_fn_state_dict", "optimizer_state_dict"] and ck["global_step"] == int(g["global_step"]) == 2
+    sd = ck["network_fn_state_dict"]
+    assert list(sd) == [str(k) for k in g["state_dict_keys"]] and all(k.startswith("module.") for k in sd)
+    assert len(ck["optimizer_state_dict"]["state"]) == int(g["optimizer_state_entries"]) > 20           # Adam moments of every live tensor
+    cfg = cfg_from(g)
+    lcfg = L.Cfg(cfg.netdepth, cfg.netwidth, cfg.multires, cfg.multires_views, cfg.h_alpha_size, cfg.h_rgb_size, cfg.n_flows)
+    layout, n_params = cfnerf_amd.param_layout(lcfg)
+    ours = set(layout) | set(api.flow_buffers(cfg.n_flows))
+    assert {k[len("module."):] for k in sd} == ours, {k[len("module."):] for k in sd} ^ ours
+    shapes = O.param_shapes(cfg)
+    for k, shp in shapes.items():
+        v = sd["module." + k]
+        assert tuple(v.shape) == tuple(shp) and v.dtype == torch.float32, k
+        assert layout[k][1] == v.numel()
+    for k, v in sd.items():
+        f = v.reshape(-1)
+        assert f.numel() == int(g["numel." + k])
+        close(f[:4].double(), g["head." + k], atol=0, rtol=0, what="head " + k)
+        close(f.double().sum(), g["sum." + k], atol=0, rtol=0, what="sum " + k)
+    for k, v in api.flow_buffers(cfg.n_flows).items():                       # the buffers this build writes ARE the reference's
+        assert torch.equal(v.to(sd["module." + k].dtype), sd["module." + k]), k
+    p = {k: sd["module." + k].clone() for k in shapes}
+    ea, er = T(g["sample_alpha"]).clone(), T(g["sample_rgb"]).clone()
+    ea[-1] = 0
+    er[-1] = 0
+    rays = T(g["rays"])
+    e = O.render(p, int(g["H"]), int(g["W"]), float(g["focal"]), cfg, ea, er, False, rays=(rays[0], rays[1]), t_rand=None)
+    close(e["rgb_map"], g["rgb_map_eval"], atol=5e-6, rtol=5e-5, what="rgb_map_eval")
+    close(e["depth_map"], g["depth_map_eval"], atol=5e-6, rtol=5e-5, what="depth_map_eval")
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/model"), reason="the reference only exists in the build container")
+def test_the_references_loader_accepts_a_checkpoint_with_this_builds_key_set(tmp_path):
+    """The reverse direction, build container only: a dict with exactly the keys this build's save_checkpoint writes (param_layout +
+    flow_buffers under the `module.` prefix; values: the oracle's generator) in the reference's checkpoint format goes through the REAL
+    reference's create_nerf(ft_path=...) - its loader lines RUN:345-378 - which resumes at that global_step with those weights."""
+    import os
+    import subprocess
+    import sys
+    import cfnerf_amd
+    from cfnerf_amd import _lib as L
+    from cfnerf_amd import api
+    from conftest import GOLDEN, ROOT
+    cfg = O.OracleCfg(netwidth=64, netdepth=4, K_samples=3)
+    lcfg = L.Cfg(cfg.netdepth, cfg.netwidth, cfg.multires, cfg.multires_views, cfg.h_alpha_size, cfg.h_rgb_size, cfg.n_flows)
+    layout, _ = cfnerf_amd.param_layout(lcfg)
+    p = O.make_params(cfg, 91)
+    assert list(p) == list(layout)
+    sd = {"module." + k: v for k, v in p.items()}
+    sd.update({"module." + k: v for k, v in api.flow_buffers(cfg.n_flows).items()})
+    path = str(tmp_path / "{:06d}_{:02d}.tar".format(777, 1))
+    torch.save({"global_step": 777, "network_fn_state_dict": sd, "optimizer_state_dict": {}}, path)      # = api.save_checkpoint's dict
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {GOLDEN!r})\n"
+        "import make_golden as MG\n"
+        "from oracle import cfnerf_oracle as O\n"
+        "R = MG.import_reference()\n"
+        "cfg = O.OracleCfg(netwidth=64, netdepth=4, K_samples=3)\n"
+        f"args = MG.ref_args(cfg, {str(tmp_path)!r}, K_samples=3, ft_path={path!r}, no_reload=False)\n"
+        "kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)\n"
+        "assert start == 777, start\n"
+        "sd = kw_train['network_fn'].state_dict()\n"
+        f"ck = torch.load({path!r})['network_fn_state_dict']\n"
+        "assert set(sd) == set(ck), set(sd) ^ set(ck)\n"
+        "assert all(torch.equal(sd[k], ck[k].to(sd[k].dtype)) for k in sd)\n"
+        "print('LOADED', len(sd))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "LOADED" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
