@@ -964,6 +964,16 @@ def step_link_by_link(c, name):
     rgb_o = r64["rgb_map"].detach().clone().requires_grad_(True)
     (Go,) = torch.autograd.grad(O.train_loss(rgb_o, d(c["target"]), r64["loss_entropy"].detach(), K, beta1)["loss"], rgb_o)
     amp = rms(Gh, Go) / max(rms(tr.rgb_map.cpu(), r64["rgb_map"].detach()), 1e-300)
+    # ... and that excess IS the loss's steepness, as a checked statement: the loss gradient as an explicit function of rgb_map (bandwidth
+    # path included), its Jacobian at the fp64 forward applied to (HIP rgb_map - fp64 rgb_map) accounts for the difference of the two loss
+    # gradients up to the second-order remainder - the two cotangents differ because the two FORWARD POINTS differ, by the loss's own J
+    from util_hip import kde_loss_gradient
+    Gfn = lambda x: kde_loss_gradient(x, d(c["target"]), K)
+    assert rel(Gfn(rgb_o.detach()), Go) <= 1e-9, "the explicit loss gradient is not the oracle's"
+    delta = tr.rgb_map.detach().cpu().double() - rgb_o.detach()
+    _, Jd = torch.autograd.functional.jvp(Gfn, rgb_o.detach(), delta)
+    lin = float(((Gh - Go - Jd) ** 2).sum().sqrt() / ((Gh - Go) ** 2).sum().sqrt().clamp_min(1e-300))
+    assert lin <= 0.25 or rms(Gh, Go) <= 2e-6, f"d loss / d rgb_map moved by {rms(Gh, Go):.1e} between the two forward points, of which the loss's Jacobian explains only {1 - lin:.0%}"
     # (c) the backward, same cotangent on both sides
     Ghf = Gh.float()
     g_iso = hip_bwd(Ghf, bool(beta1))
@@ -987,7 +997,7 @@ def step_link_by_link(c, name):
         if e_max > worst[1]:
             worst = (k, e_max, n_max)
     print(f"{name}: rgb_map HIP vs fp64 {rel(tr.rgb_map.cpu(), r64['rgb_map'].detach()):.1e}; the loss gradient moves by {rms(Gh, Go):.1e} (RMS) between the two forward points "
-          f"= {amp:.0f} x the rgb_map difference; isolated backward: worst tensor {worst[0]} {worst[1]:.1e} (fp32 CPU oracle {worst[2]:.1e})")
+          f"= {amp:.0f} x the rgb_map difference ({1 - lin:.1%} of it is the loss's Jacobian applied to that difference); isolated backward: worst tensor {worst[0]} {worst[1]:.1e} (fp32 CPU oracle {worst[2]:.1e})")
     return dict(hip_bwd=hip_bwd, masks=masks, keys=keys, d=d, rel=rel)
 
 

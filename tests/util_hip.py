@@ -235,6 +235,23 @@ G_ALPHA_X = 2.0            # the density ("alpha") path is the ill-conditioned o
 G_CAP_OTHER = 2e-4         # every tensor OUTSIDE the alpha path: the calibration can only tighten the fixed bound of round 2, never loosen it
 
 
+def kde_loss_gradient(rgbs, target, K, n_total=None):
+    """d loss_nll / d rgb_map of the reference's KDE loss (RUN:1032-1042) as an EXPLICIT function of rgb_map [N,3,K], differentiable ONCE
+    MORE with the bandwidth's own dependence on rgb_map included: the reference detaches the bandwidth from the loss's graph, so autograd's
+    double-backward of O.train_loss misses the path through it, while the gradient VALUE moves with it.  Its Jacobian applied to the
+    difference of two forwards is how far the loss gradient moves between them (tests/test_hip_train.py: the K = 2 link-by-link step)."""
+    import math
+    n, eps = K, 1e-05
+    d = rgbs - target[..., None]
+    bw = float(torch.pow(torch.tensor(0.8 / n), torch.tensor(-1 / 7)))           # (fp32 constants, as RUN:1036,1039 make them)
+    c2pi = float(torch.pow(torch.tensor(2 * math.pi), -1.5))
+    H = (torch.std(rgbs, -1) * n / (n - 1) * bw + eps)[..., None]
+    r1 = torch.exp(-(d * d) / (2 * H * H))
+    r2 = c2pi / H
+    m = (r1 * r2).mean(-1, keepdim=True) + eps
+    return (r1 * r2) * d / (H * H) / m / (K * 3.0 * (n_total or rgbs.shape[0]))
+
+
 ONE_RAY_COVERAGE = 0.1     # a one-ray gradient that lost or doubled a k-part / a tile of the ray is off by >= 0.25 of its largest entry
 
 
