@@ -484,7 +484,7 @@ void bwd_data_kernel(const BwdArgs A_, const NetTab T_) {
             epi_prefetch<NTV>(e, T.bt_hr.nt, wave, kWaves, mb_all + ((size_t)D * n_tiles + tile) * kMbStride, dbp + A.db_v, first);
             mma_any<NTV, PREC, (W > 256 ? 3 : 2)>(acc, kload(T.bt_hr), wave, kWaves, wp, wp16, act, LD);
             __syncthreads();
-            store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid);
+            store_bwd<NTV, PREC>(acc, e, T.bt_hr.nt, wave, kWaves, act, LD, A.g_v + p0 * (W / 2), W / 2, dbp + A.db_v, rows_valid, A.q4 != 0);
             __syncthreads();
         }
         // ---- 3. dfeature = dv * V[:, 0:W]        (feature_linear has no activation, MOD:176)

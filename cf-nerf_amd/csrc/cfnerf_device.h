@@ -557,6 +557,31 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[2][NTW], co
     }
 }
 
+// The Q4 stash of a layer WITHOUT the LDS write: acc (+ bias) leaves as pieces straight from the registers, the tile in LDS is written later
+// by a plain store_tiles (STASH 0) of the same accumulators.  For the feature head of the train forward: its inputs (the last trunk activations)
+// must stay in the LDS tile until the h_alpha head has read them too, and with BOTH heads' accumulators live the Q4 stores of the combined
+// epilogue spilt 13 - 37 VGPRs (rounds 5 - 6); issued right after the feature head's own MFMA loop - before the h_alpha accumulators exist -
+// they cost no register.  The bias is in the accumulators already (acc_init), there is no activation: the same values as store_tiles<..., Q4>.
+template <int NTW>
+__device__ __forceinline__ void stash_tiles_q4(const f32x16 (&acc)[2][NTW], const SubL s, int nt0, int nts, float* __restrict__ gdst, int gld) {
+    const int lane = lane_id_opaque();
+    const __amdgpu_buffer_rsrc_t sink = slab_rsrc(gdst, gdst != nullptr ? kTileM : 0, gld);      // (no stash: empty descriptor, the stores are dropped)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = nt0 + j * nts;
+        if (nt >= (int)s.nt) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * g + e]);
+                q4_store(v, sink, lane, q4_piece(i, nt, g, gld >> 5));
+            }
+    }
+}
+
 // MAY_STASH: the row-major element stores may be needed (a stream that is never copied out by stash_rows); Q4: the stream takes the Q4
 // layout (a compile-time property of the kernel variant: two epilogue flavours inside ONE kernel spilt 20-30 VGPRs of the train forward) -
 // gdst is then the TILE's base, the same address as its row-major slab.

@@ -55,8 +55,9 @@ inline void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
     const int ic = enc_ch(c.multires), icv = enc_ch(c.multires_views), skip = skip_layer(D);
     char key[64];
     const int one_row[1] = {0};
-    // operand layouts (DwTile::lay: bit 0 = dY, bit 1 = X): with whole tiles in fp32 mode (Stash::q4) the trunk streams h[l], g_h[l] and
-    // g_feat are Q4 (cfnerf_device.h); feature / v / g_v, the encodings, the narrow heads and theta / g_theta stay row-major
+    // operand layouts (DwTile::lay: bit 0 = dY, bit 1 = X): with whole tiles in fp32 mode (Stash::q4) every WIDE stream - h[l], feature, v and
+    // their pre-activation gradients g_h[l], g_feat, g_v - is Q4 (cfnerf_device.h; round 5: the trunk streams, round 6: feature / v / g_v);
+    // the encodings, the narrow heads and theta / g_theta stay row-major
     const int qY = 1, qX = 2;
     const bool Q = q.q4;
     for (int l = 0; l < D; ++l) {
@@ -77,10 +78,10 @@ inline void build_dw_jobs(const cfnerf_cfg& c, const ParamLayout& L, const Stash
     { const uint32_t dst[1] = {(uint32_t)L.off("feature_linear.weight")}; add_job(big, small, q.g_feat, W, W, W, hlast, W, W, W, 1, one_row, dst, W, 0, 0, qY | qX, Q); }
     {
         const uint32_t dst[1] = {(uint32_t)L.off("views_linears.0.weight")};
-        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0);
-        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W);
+        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.feat, W, W, W, 1, one_row, dst, W + icv, 0, 0, qY | qX, Q);
+        add_job(big, small, q.g_v, W / 2, W / 2, W / 2, q.gd, 32, 32, icv, 1, one_row, dst, W + icv, W, 0, qY, Q);
     }
-    { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0); }
+    { const uint32_t dst[1] = {(uint32_t)L.off("h_rgb_linear.weight")}; add_job(big, small, q.g_hr, HR, HR, HR, q.v, W / 2, W / 2, W / 2, 1, one_row, dst, W / 2, 0, 0, qX, Q); }
     {
         const int rows[4] = {0, 9 * F, 12 * F, 15 * F};
         const uint32_t dst[4] = {(uint32_t)L.off("flows_rgb.amor_d.weight"), (uint32_t)L.off("flows_rgb.amor_diag1.0.weight"),
@@ -185,7 +186,9 @@ inline void balance_small_splits(std::vector<DwTile>& tiles, int n_cu, int64_t P
     if (tiles.empty()) return;
     int cap = kDwSlots;
     while (cap > 1 && P / cap < 512) cap >>= 1;              // at least 512 points per block
-    auto cost = [](const DwTile& t) { return (double)(small_stage_cols(t) + 32); };
+    // (+ 64 columns' worth of fixed cost per stage: same-box sweep over 32 / 64 / 100 / 150 / 220 in round 6 - weight-gradient stage 1.1913 /
+    //  1.1834 / 1.1879 / 1.1917 / 1.1926 ms at C2; rounds 3 - 5 used 32.  A narrow tile's 8-KB stage takes 0.94 us where a 24-KB one takes 1.64)
+    auto cost = [](const DwTile& t) { return (double)(small_stage_cols(t) + 64); };
     double total = 0;
     for (const DwTile& t : tiles) total += cost(t);
     const int slots = 2 * n_cu;

@@ -326,10 +326,19 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 float* const st_feat = A.st_feat;
                 fetched_together(s_vf.w_off, s_ha.w_off, st_ha, st_feat);
                 acc_init(accF, bias_n);
-                acc_zero(accA);
                 load_bias<C::NTV>(s_vf, wave, kWv, wp, bias_v);
-                mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
-                mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);
+                if (Q4) {
+                    // the feature head first: its stash leaves as Q4 pieces straight from the accumulators (bias already in them, no activation)
+                    // BEFORE the h_alpha accumulators exist - inside the combined epilogue below those stores spilt 13 - 37 VGPRs (rounds 5 - 6)
+                    mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);
+                    stash_tiles_q4<C::NTW>(accF, tl_ft, wave, kWv, st_feat ? st_feat + p0 * W : nullptr, W);
+                    acc_zero(accA);
+                    mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
+                } else {
+                    acc_zero(accA);
+                    mma_ksplit<PREC, 2>(accA, s_ha, wave, kWv, wp, wp16, act, LD);
+                    mma_any<C::NTW, PREC, 2>(accF, tl_ft, wave, kWv, wp, wp16, act, LD);
+                }
                 __syncthreads();                     // every wave is done reading h
                 {
                     const int lo = lane_id_opaque();
@@ -372,10 +381,10 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                     }
                 }
                 __syncthreads();
-                // (feature and v stay row-major in every variant: with accF AND accA live, the Q4 stores of this epilogue spilt 13 VGPRs)
-                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows, true>(accF, tl_ft, wave, kWv, wp, act, LD, 0,
-                                              st_feat ? st_feat + p0 * W : nullptr, W, rows_valid);
+                // (Q4 variant: the feature stash has left from the registers above; here the tile only goes to LDS)
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds && !Q4;
+                store_tiles<C::NTW, ACT_NONE, PREC, false, TRAIN && !kRows && !Q4, true>(accF, tl_ft, wave, kWv, wp, act, LD, 0,
+                                              (st_feat && !Q4) ? st_feat + p0 * W : nullptr, W, rows_valid);
                 __syncthreads();
                 if (kRows && st_feat != nullptr) stash_rows<W, kThr>(act, LD, st_feat + p0 * W, rows_valid);
             }
@@ -404,8 +413,8 @@ void fused_fwd_kernel(const FwdArgs A_, const NetTab T_) {
                 mma_any<C::NTV, PREC, 2>(acc, s_vd, wave, kWv, wp, wp16, act, LD);
                 __syncthreads();
                 uint32_t* mb = (te_mb0 != nullptr) ? te_mb0 + (size_t)Dn * te_mb_step : nullptr;
-                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds;
-                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true>(acc, s_vf, wave, kWv, wp, act, LD, 0,
+                constexpr bool kRows = TRAIN && PREC == PREC_F32 && kStashFromLds && !Q4;
+                store_tiles<C::NTV, ACT_RELU, PREC, TRAIN, TRAIN && !kRows, true, Q4>(acc, s_vf, wave, kWv, wp, act, LD, 0,
                                                     st_v ? st_v + p0 * (W / 2) : nullptr, W / 2, rows_valid, mb);
                 __syncthreads();
                 if (kRows && st_v != nullptr) stash_rows<W / 2, kThr>(act, LD, st_v + p0 * (W / 2), rows_valid);

@@ -83,7 +83,7 @@ def q4_to_rows(flat, cols):
     return flat.reshape(-1, 2, nt, 4, 2, 32, 4).permute(0, 1, 3, 4, 6, 2, 5).reshape(-1, cols)
 
 
-Q4_STREAMS = ("h", "g_h", "g_feat")
+Q4_STREAMS = {"h": 1, "g_h": 1, "g_feat": 1, "feat": 1, "v": 2, "g_v": 2}        # wide streams that take the Q4 layout -> netwidth / this = their columns
 
 
 def stash_copy(net, name, layer, n, keep=None):
@@ -101,7 +101,7 @@ def stash_copy(net, name, layer, n, keep=None):
     q4 = hooks.lib().cfnerf_debug_stash_q4
     q4.restype, q4.argtypes = C.c_int, [C.c_void_p]
     if name in Q4_STREAMS and q4(net.handle) == 1:
-        out = q4_to_rows(out, net.W).reshape(-1)
+        out = q4_to_rows(out, net.W // Q4_STREAMS[name]).reshape(-1)
     return (out if keep is None else out[keep[0]:keep[1]]).cpu()
 
 
