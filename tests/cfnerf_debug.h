@@ -30,8 +30,9 @@ CFNERF_API int64_t cfnerf_debug_copy_stash(cfnerf_model* m, const char* name, in
 /* 1 if the last STASH forward wrote its trunk streams ("h", and its backward "g_h", "g_feat") in the Q4 layout (csrc/cfnerf_device.h:
  * whole 64-point tiles, fp32 mode), 0 if row-major, -1 without a stash; tests/util_hip.py::q4_to_rows undoes the layout */
 CFNERF_API int cfnerf_debug_stash_q4(cfnerf_model* m);
-/* the weight-gradient tiles of a configuration at P points: 12 int32 per tile + 4 destination segments each */
-CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles);
+/* the weight-gradient tiles of a configuration at P points for a stash layout (q4 as in cfnerf_debug_dw_blocks): 20 int32 per tile
+ * {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[4], dst_ld, dst_col, row_f, late, lay, 0, 0, 0} + 4 destination segments each */
+CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int q4, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles);
 /* the blocks of that plan for a point count and CU count: 5 int64 per block {kind, tile, split, pb, pe}, per tile its split count,
  * per parameter tensor the slot count of the reduction and (seg_early, may be NULL) whether every job that feeds it belongs to the big launch
  * in EITHER stash layout.  q4: the layout of the wide streams the plan is made for (1 / 0 as the product decides it: fp32 mode and whole

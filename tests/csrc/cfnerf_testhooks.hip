@@ -88,9 +88,9 @@ CFNERF_API int cfnerf_debug_operand(const cfnerf_cfg* cfg, const char* name, int
 }
 
 // ---- debug / test helper (not part of include/cfnerf.h): the weight-gradient tile plan of a configuration, for the
-// CPU test that every weight element is covered exactly once.  16 int32 per tile:
-// {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[0..3], dst_ld, dst_col, 0, 0} followed by 4 uint32 seg_dst in a second array.
-CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
+// CPU test that every weight element is covered exactly once.  20 int32 per tile:
+// {is_big, n0, k0, N, K, gk, wk, nseg, seg_row[0..3], dst_ld, dst_col, row_f, late, lay, 0, 0, 0} followed by 4 uint32 seg_dst in a second array.
+CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int q4, int32_t* tiles_out, uint32_t* segdst_out, int max_tiles) {
     if (!cfg || validate_cfg(*cfg)) return CFNERF_E_UNSUPPORTED;
     ParamLayout L = build_layout(*cfg);
     Stash q;                                   // fake, distinct operand bases: only the geometry is reported
@@ -98,6 +98,7 @@ CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
     const size_t step = size_t(1) << 36;
     float** ptrs[] = {&q.enc, &q.gd, &q.h, &q.feat, &q.v, &q.ha, &q.hr, &q.theta, &q.g_theta, &q.g_hr, &q.g_ha, &q.g_v, &q.g_feat, &q.g_h};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) *ptrs[i] = base + i * step;
+    q.q4 = q4 < 0 ? (P % kTileM == 0) : (q4 != 0);        // the layout the plan is made for (see cfnerf_debug_dw_blocks)
     std::vector<DwTile> big, small;
     build_dw_jobs(*cfg, L, q, P, big, small);
     for (float** pp : ptrs) *pp = nullptr;
@@ -105,10 +106,11 @@ CFNERF_API int cfnerf_debug_dw_plan(const cfnerf_cfg* cfg, int64_t P, int32_t* t
     for (int pass = 0; pass < 2; ++pass)
         for (const DwTile& t : (pass == 0 ? big : small)) {
             if (n >= max_tiles) return -n;
-            int32_t* o = tiles_out + 16 * n;
+            int32_t* o = tiles_out + 20 * n;
             o[0] = pass == 0; o[1] = t.n0; o[2] = t.k0; o[3] = t.N; o[4] = t.K; o[5] = t.gk; o[6] = t.wk; o[7] = t.nseg;
             for (int g = 0; g < 4; ++g) { o[8 + g] = t.seg_row[g]; segdst_out[4 * n + g] = t.seg_dst[g]; }
             o[12] = t.dst_ld; o[13] = t.dst_col; o[14] = t.row_f; o[15] = t.late;
+            o[16] = t.lay; o[17] = 0; o[18] = 0; o[19] = 0;
             ++n;
         }
     return n;

@@ -275,20 +275,22 @@ def test_seeded_construction_replays_the_reference_rng_stream(golden, tag):
 @pytest.mark.parametrize("W,D,ha,hr", [(256, 8, 32, 64), (64, 8, 32, 64), (128, 6, 32, 32), (512, 8, 64, 64), (256, 3, 64, 32), (512, 16, 32, 64), (192, 8, 32, 64), (320, 8, 32, 64),
                                        (384, 6, 64, 32), (448, 8, 32, 64), (256, 8, 96, 128), (64, 8, 128, 96), (512, 8, 96, 128)])
 @pytest.mark.parametrize("F,mr,mrv", [(4, 10, 4), (3, 10, 4), (1, 10, 4), (4, 6, 2), (4, 1, 1), (3, 10, 1), (4, 4, 4)])
-def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr, F, mr, mrv):
-    """Host logic of the backward: the big / small dW tiles (wave arrangement GN x GK of the small kernel included)
-    must write every live weight element exactly once per split slot and never touch biases or dead tensors."""
+@pytest.mark.parametrize("q4", [0, 1])
+def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr, F, mr, mrv, q4):
+    """Host logic of the backward: the big / small dW tiles (wave arrangement GN x GK of the small kernel included) must write every live
+    weight element exactly once per split slot and never touch biases or dead tensors - in BOTH stash layouts (row-major: bf16x3 / ragged
+    sample tables; Q4: fp32 with whole tiles)."""
     import hooks
     lib = hooks.lib()
     lib.cfnerf_debug_dw_plan.restype = C.c_int
-    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
+    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
     cfg = L.Cfg(D, W, mr, mrv, ha, hr, F)
     cap = 4096
-    tiles = (C.c_int32 * (16 * cap))()
+    tiles = (C.c_int32 * (20 * cap))()
     segdst = (C.c_uint32 * (4 * cap))()
-    n = lib.cfnerf_debug_dw_plan(C.byref(cfg), 131072, tiles, segdst, cap)
+    n = lib.cfnerf_debug_dw_plan(C.byref(cfg), 131072, q4, tiles, segdst, cap)
     assert n > 0
-    t = np.ctypeslib.as_array(tiles).reshape(cap, 16)[:n]
+    t = np.ctypeslib.as_array(tiles).reshape(cap, 20)[:n]
     sd = np.ctypeslib.as_array(segdst).reshape(cap, 4)[:n]
     layout, n_params = cfnerf_amd.param_layout(cfg)
     count = np.zeros(n_params, np.int32)
@@ -314,6 +316,8 @@ def test_weight_gradient_plan_covers_every_weight_once(W, D, ha, hr, F, mr, mrv)
         base = np.array([int(dst[g]) for g in range(4)], np.int64)[seg] + (ns - np.array(seg_row)[seg]) * dst_ld + dst_col
         idx = (base[:, None] + ks[None, :]).reshape(-1)
         np.add.at(count, idx, 1)
+        lay = int(row[16])
+        assert (q4 or lay == 0) and (not is_big or lay in (0, 3))        # a big tile takes both operands in ONE layout
     dead = ("alpha_linear.", "alpha_std_linear.", "flows_alpha.amor_d.")
     for key, (off, numel) in layout.items():
         c = count[off:off + numel]
@@ -337,7 +341,7 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     fn.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                    C.POINTER(C.c_int32), C.c_int]
     lib.cfnerf_debug_dw_plan.restype = C.c_int
-    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
+    lib.cfnerf_debug_dw_plan.argtypes = [C.POINTER(L.Cfg), C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]
     cfg = L.Cfg(D, W, 10, 4, 32, 64, 4)
     cap = 20000
     blocks = (C.c_int64 * (5 * cap))()
@@ -346,10 +350,10 @@ def test_weight_gradient_blocks_partition_the_points(W, D, P, n_cu):
     n = fn(C.byref(cfg), P, n_cu, -1, blocks, cap, tile_ns, seg_ns, None, 256)
     assert n > 0
     b = np.ctypeslib.as_array(blocks).reshape(cap, 5)[:n]
-    tiles = (C.c_int32 * (16 * 1024))()
+    tiles = (C.c_int32 * (20 * 1024))()
     segdst = (C.c_uint32 * (4 * 1024))()
-    nt = lib.cfnerf_debug_dw_plan(C.byref(cfg), P, tiles, segdst, 1024)
-    t = np.ctypeslib.as_array(tiles).reshape(1024, 16)[:nt]
+    nt = lib.cfnerf_debug_dw_plan(C.byref(cfg), P, -1, tiles, segdst, 1024)
+    t = np.ctypeslib.as_array(tiles).reshape(1024, 20)[:nt]
     sd = np.ctypeslib.as_array(segdst).reshape(1024, 4)[:nt]
     ns = np.ctypeslib.as_array(tile_ns)[:nt]
     layout, _ = cfnerf_amd.param_layout(cfg)
