@@ -806,7 +806,7 @@ def main():
         fl = wl.fwd_flops()                     # forward GEMM FLOPs of one launch of the fused forward kernel
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
         traffic, mfma_busy, src = None, None, None
-        for prof in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
+        for prof in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     tj = json.load(f)[f"{name}:{mode}"]

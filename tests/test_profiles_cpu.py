@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r05"
+TAG = "r06"
 
 
 def line(name):
@@ -18,7 +18,7 @@ def line(name):
 
 
 @pytest.mark.parametrize("name,workload", [("default", "C2"), ("c2", "C2"), ("c3", "C3"), ("c4", "C4"), ("w512", "W512"), ("eval", "C2"), ("c5", "C5"), ("c1", "C1"),
-                                           ("k64", "K64"), ("2ranks_same_gpu", "C2")])
+                                           ("k64", "K64"), ("n8192", "N8192"), ("2ranks_same_gpu", "C2")])
 def test_bench_lines_carry_the_contract(name, workload):
     d = line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -35,6 +35,8 @@ def test_bench_lines_carry_the_contract(name, workload):
         p = d["psnr"]
         assert p["n_gpus"] == 2 and p["global_batch"] == 2048 and p["vs_single_process"]["agree"] is True and p["vs_single_process"]["abs_psnr_diff_db"] <= 0.05
         assert p["vs_oracle"]["agree"] is True and p["vs_reference_run"]["agree"] is True
+    if name == "n8192":      # 8192 rays per optimiser step walked in 8 slices of 1024 (cfnerf_render_bwd_accumulate): within 2 % of C2's rays/s
+        assert "8 slices of 1024" in d["config"]["workload"] and abs(d["value"] / line("c2")["value"] - 1.0) <= 0.02
     if name == "k64":
         assert "K=64" in d["config"]["workload"] and d["kernel_ms"]["bwd_tail"] > 0.15      # the reference's default latent count (RUN:631)
     if name == "default":
@@ -69,3 +71,30 @@ def test_traffic_is_the_pmc_figure_on_file():
     k = t["C2:train"]
     assert abs(k["hbm_bytes_per_launch"] - (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024) <= 1e-6 * k["hbm_bytes_per_launch"]
     assert os.path.exists(os.path.join(P, f"{TAG}_pmc_summary.txt"))
+
+
+def test_design_kernel_table_quotes_the_committed_csvs():
+    """every row of the kernel table (between the KERNEL-TABLE markers) names a kernel, the committed
+    rocprofv3 --kernel-trace --stats CSV it was read from and the average it quotes; the CSV must hold that number (0.5 %), and the
+    fraction of the 157.3 TF fp32-MFMA peak quoted next to a GEMM kernel must follow from it."""
+    import re
+    with open(os.path.join(ROOT, "DESIGN.md")) as f:
+        text = f.read()
+    block = text[text.index("<!-- KERNEL-TABLE"):text.index("<!-- /KERNEL-TABLE -->")]
+    rows = [r for r in block.splitlines() if r.startswith("| `")]
+    assert len(rows) >= 7
+    gflop = {"fused_fwd_kernel<256": 160.99, "bwd_data_kernel<256": 160.99, "dw_big_kernel": 146.0, "dw_small_kernel": 15.5, "fused_fwd_kernel<512": 308.57}
+    for r in rows:
+        cells = [c.strip() for c in r.strip("|").split("|")]
+        kernel = re.match(r"`([^`]+)`", cells[0]).group(1)
+        csv_name = re.match(r"`([^`]+)`", cells[1]).group(1)
+        quoted_ms = float(re.match(r"([0-9.]+)", cells[2]).group(1))
+        with open(os.path.join(P, csv_name)) as f:
+            hit = [x for x in csv.DictReader(f) if kernel in x["Name"]]
+        assert len(hit) == 1, (kernel, csv_name, [x["Name"][:60] for x in hit])
+        avg_ms = float(hit[0]["AverageNs"]) / 1e6
+        assert abs(quoted_ms - avg_ms) <= 0.005 * avg_ms + 5e-5, (kernel, quoted_ms, avg_ms)
+        for key, gf in gflop.items():
+            if kernel.startswith(key) and re.match(r"0\.[0-9]+", cells[3]):
+                frac = float(re.match(r"(0\.[0-9]+)", cells[3]).group(1))
+                assert abs(frac - gf / avg_ms / 157.3) <= 0.006, (kernel, frac, gf / avg_ms / 157.3)

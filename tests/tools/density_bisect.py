@@ -8,9 +8,10 @@ values the forward left in the stash.  For one ray with a one-hot cotangent this
   E   : torch autograd in fp64 of the same function of the same fp32 inputs (the exact answer at the HIP forward point),
   T32 : torch autograd in fp32 of it (what the reference's arithmetic delivers),
 per sample, as column sums (= the bias gradients: where a ray's terms cancel) and as the sums weighted with h_alpha (= the head weights).
-Then the kernel's own formula (g T - suffix / x, the flow adjoint on the recomputed chain) is evaluated in fp64 with ONE ingredient at a
+Then the formula of rounds 1 - 5 (g T - suffix / x, the flow adjoint on the recomputed chain) is evaluated in fp64 with ONE ingredient at a
 time replaced by what the kernel really has (the stashed fp32 e, the stashed fp32 T, fp32 colours, an fp32 suffix scan, ...): the
-ingredient whose substitution reproduces the kernel's error is the defect."""
+ingredient whose substitution reproduces the kernel's error is the defect - it was the product scan's T (profiles/r06_density_bisect.txt).
+"alternative: ..." rows: candidate replacements fed the kernel's own stash; D32tree is what comp_adjoint_D (csrc/cfnerf_device.h) does now."""
 import argparse
 import json
 import os
@@ -94,7 +95,6 @@ def autograd_ref(d, G, eps_a, mean, std, wb, dt):
     Lv, fw = density_loss(th, eps_a.to(dt), m, s, c, d["z"].to(dt), dnorm, G, wb)
     gth, gm, gs = torch.autograd.grad(Lv, [th, m, s])
     thd = th.detach()
-    scale = torch.ones(12, dtype=dt)
     g = gth.clone()
     g[:, :8] = g[:, :8] * (1.0 - thd[:, :8] ** 2)            # the diagonals chain through their tanh (MOD:341-348): g_theta is pre-tanh
     return g, float(gm), float(gs), {k: v.detach() for k, v in fw.items()}
@@ -102,7 +102,7 @@ def autograd_ref(d, G, eps_a, mean, std, wb, dt):
 
 def kernel_formula(d, G, eps_a, mean, std, wb, sub):
     """The tail kernel's own formula (cfnerf_tail.hip) in fp64, with the ingredients named in `sub` replaced by what the kernel has.
-    sub: set of {"e", "T", "c32", "csig_hw", "raw3", "suffix32", "comp32", "flow32"}"""
+    sub: set of {"e", "T", "c32", "raw3", "suffix32", "comp32", "flow32"}"""
     dt = F64
     th = d["theta"][:, 96:108].to(dt)
     S, K = d["raw"].shape[0], d["raw"].shape[1]
@@ -135,7 +135,6 @@ def kernel_formula(d, G, eps_a, mean, std, wb, sub):
             g = g - f(Gt).sum(-1)[None]
         w = f(alpha) * f(T)
         gw = g * w
-        suffix = torch.flip(torch.cumsum(torch.flip(gw, [0]), 0), [0]) - gw
         suffix = torch.cat([torch.flip(torch.cumsum(torch.flip(gw, [0]), 0), [0])[1:], torch.zeros(1, K)], 0)
         dalpha = g * f(T) - suffix / f(x)
         sg = torch.sigmoid(f(raw3))

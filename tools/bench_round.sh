@@ -14,6 +14,7 @@ python bench.py $B --steps 30 --config W512 > "$O/bench_${T}_w512.json" 2>> "$O/
 python bench.py $B --steps 50 --config C1 > "$O/bench_${T}_c1.json" 2>> "$O/bench_${T}.err"
 python bench.py $B --steps 3 --warmup 1 --config C5 > "$O/bench_${T}_c5.json" 2>> "$O/bench_${T}.err"
 python bench.py $B --steps 30 --config K64 > "$O/bench_${T}_k64.json" 2>> "$O/bench_${T}.err"
+python bench.py $B --steps 10 --warmup 3 --config N8192 > "$O/bench_${T}_n8192.json" 2>> "$O/bench_${T}.err"
 # the N > 1 line with everything in it (psnr + vs_single_process, comm, rank_skew, cpu_baseline): two ranks on ONE GPU over gloo, a code-path run
 CFNERF_BENCH_SAME_GPU=1 python bench.py --gpus 2 --steps 20 --psnr-steps 500 > "$O/bench_${T}_2ranks_same_gpu.json" 2>> "$O/bench_${T}.err"
 for f in "$O"/bench_${T}_*.json; do python - "$f" <<'PY'
