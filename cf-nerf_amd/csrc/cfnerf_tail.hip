@@ -17,8 +17,8 @@ namespace cfnerf {
 
 // ================================================================================================
 // 2. tail: adjoint of raw2outputs (RUN:424-452) and of the K flows (FLW:225-268, MOD:263-286).
-//    One wave per ray, lane = sample, chunks of 64 samples walked back-to-front so the suffix sums
-//    of the transmittance adjoint are a reverse wave scan + a per-k carry.
+//    One wave per ray, lane = sample, chunks of 64 samples walked back-to-front so the transmittance
+//    adjoint (comp_adjoint_D, cfnerf_device.h) is a reverse wave scan + a per-k carry.
 // Adjoint of the four conditional Sylvester flows (FLW:225-268, MOD:401-413) for ONE (point, latent sample): recomputes the
 // forward keeping each step's input and tanh, then walks it backwards.  In: th = the point's flow parameters, e = the latent,
 // ga / gz = d loss / d (alpha, rgb) flow outputs (activation and entropy-Jacobian terms already added), cE = the weight of the
