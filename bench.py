@@ -716,6 +716,24 @@ def main():
         ws.net.release_workspace()
         del ws
 
+    # a batch larger than the workspace the caller lends: N_rand 8192 walked in 8 slices of 1024 (Trainer(max_rays_per_launch=1024),
+    # cfnerf_render_bwd_accumulate) - the reference trains any N_rand (RUN:88-100,602).  One rank, a second of run time; guarded like `eval`
+    sliced = None
+    if extras and world == 1:
+        try:
+            wl.__dict__.pop("trainer", None)
+            wl.net.release_workspace()
+            w8 = Workload("N8192", "train", rank, world, dev, "fp32", False)
+            n8 = max(3, min(10, args.steps))
+            dt8 = timed(w8, n8, 2, sync)
+            sliced = {"workload": w8.describe("fp32"), "value": w8.n * n8 / dt8, "unit": "rays/s", "ms_per_step": dt8 / n8 * 1e3,
+                      "slices": w8.launches_per_step(), "workspace_bytes": int(w8.net._ws.numel()),
+                      "step_frac_of_peak": 3 * w8.fwd_flops() * w8.launches_per_step() / (dt8 / n8) / 1e12 / FP32_MFMA_PEAK_TF}
+            w8.net.release_workspace()
+            del w8
+        except Exception as e:
+            sliced = {"error": f"{type(e).__name__}: {e}"}
+
     # the coarse + fine sampling EXTENSION (BASELINE configs 2/3/5 are worded "64 + 128"; the reference has no second pass, so
     # this is NOT the parity path and never the headline): coarse 64 -> sample_pdf -> fine 64 + 128, both loss terms
     hier = None
@@ -856,6 +874,8 @@ def main():
             out["config4_k16"] = cfg4
         if stress is not None:
             out["stress_w512"] = stress
+        if sliced is not None:
+            out["sliced_batch_n8192"] = sliced
         if hier is not None:
             out["alt_config"] = hier
         if comm is not None:

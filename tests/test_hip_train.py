@@ -589,13 +589,14 @@ def test_full_size_train_step_properties(tag, N, K, ndc):
     model.module.release_workspace()
 
 
-@pytest.mark.parametrize("W,K,N,per,beta1", [(256, 4, 8192, 1024, 0.01), (64, 3, 96, 24, 0.05), (128, 16, 200, 64, 0.0)])
-def test_batch_walked_in_slices_equals_the_one_shot_batch(W, K, N, per, beta1):
+@pytest.mark.parametrize("W,K,N,per,beta1,world", [(256, 4, 8192, 1024, 0.01, 1), (64, 3, 96, 24, 0.05, 1), (128, 16, 200, 64, 0.0, 1), (64, 4, 120, 40, 0.02, 2)])
+def test_batch_walked_in_slices_equals_the_one_shot_batch(W, K, N, per, beta1, world):
     """A batch larger than the workspace the caller lends is walked in equal slices (Trainer(max_rays_per_launch=), the slice gradients
     added by cfnerf_render_bwd_accumulate; the reference trains any N_rand, RUN:88-100,602).  The review's case: N_rand 8192 in 8 slices
     of 1024 against ONE 8192-ray launch - gradient within the shard-additivity bound of the suite (2e-5 of the largest entry), loss
     scalars equal, the sliced run's workspace = what a 1024-ray step needs; then two optimiser steps of either form leave the same
-    parameters.  (200 rays at 64 per launch: 4 slices of 50 - the fewest EQUAL slices.)"""
+    parameters.  (200 rays at 64 per launch: 4 slices of 50 - the fewest EQUAL slices.  world = 2: one rank's shard with the multi-GPU loss
+    normalisation - nll / (3 N_total), beta1 / world on the shard's entropy - walked in slices: the slice terms still add up to the shard's.)"""
     import ctypes as C
     from cfnerf_amd import _lib as L
     cfg = O.OracleCfg(netwidth=W, K_samples=K)
@@ -609,12 +610,12 @@ def test_batch_walked_in_slices_equals_the_one_shot_batch(W, K, N, per, beta1):
     for form, mx in (("sliced", per), ("one shot", None)):
         _, _, _, model, p, _ = build_model(cfg, 5)
         net = model.module
-        tr = TR.Trainer(net, beta1=beta1, max_rays_per_launch=mx)
+        tr = TR.Trainer(net, beta1=beta1, max_rays_per_launch=mx, world_size=world)      # (world > 1 without a process group: shard semantics only)
         n_sl = tr.n_slices(N)
         g = tr.forward_backward(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps).clone()
         sc, ent, rgb = tr.scalars.clone(), tr.entropy.clone(), tr.rgb_map.clone()
         ws = int(net._ws.numel())
-        for _ in range(2):
+        for _ in range(2 if world == 1 else 0):
             tr.step(H, Wd, focal, rays, target, t_rand=t_rand, eps=eps)
         out[form] = dict(g=g, sc=sc, ent=ent, rgb=rgb, ws=ws, n_sl=n_sl, flat=net.flat.detach().clone())
         if form == "sliced":
