@@ -41,6 +41,8 @@ def test_bench_lines_carry_the_contract(name, workload):
         assert "K=64" in d["config"]["workload"] and d["kernel_ms"]["bwd_tail"] > 0.15      # the reference's default latent count (RUN:631)
     if name == "default":
         assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and "alt_precision" in d and "stress_w512" in d
+        sb = d["sliced_batch_n8192"]              # 8192 rays per step on the workspace of a 1024-ray step, within 2 % of the headline rate
+        assert sb["slices"] == 8 and sb["workspace_bytes"] < 3.5 * 2 ** 30 and abs(sb["value"] / d["value"] - 1.0) <= 0.02
         # the second half of the headline metric, in the line itself (synthetic stand-in scene) + the HIP-vs-oracle agreement
         p = d["psnr"]
         assert "synthetic stand-in for LLFF-fern" in p["scene"] and p["unit"] == "dB" and p["value"] > 30.0 and p["vs_oracle"]["agree"] is True
