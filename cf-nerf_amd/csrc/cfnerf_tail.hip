@@ -69,10 +69,11 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], GACC& gth, 
         gth.add((0 * 3 + 1) * 4 + f, gu0 * t1); gth.add((0 * 3 + 2) * 4 + f, gu0 * t2); gth.add((1 * 3 + 2) * 4 + f, gu1 * t2);
         // log-det: ld_i = log(|q_i| + 1e-8), q_i = (1 - t_i^2) d1_i d2_i + 1     (FLW:251-259)
         if (cE != 0.f && valid) {
+            // q = 1 + (1 - t^2) d1 d2 >= t^2 >= 0: the diagonals are tanh outputs (|d| <= 1, MOD:341-348), so |q| = q and sign(q) = +1 - the abs / copysign
+            // of FLW:255 are the identity here (the forward keeps them: libm parity)
             const float q0 = (1.f - t0 * t0) * (d1_0 * d2_0) + 1.f, q1 = (1.f - t1 * t1) * (d1_1 * d2_1) + 1.f,
                         q2 = (1.f - t2 * t2) * (d1_2 * d2_2) + 1.f;
-            const float gq0 = cE * copysignf(1.f, q0) * t_rcp(fabsf(q0) + 1e-08f), gq1 = cE * copysignf(1.f, q1) * t_rcp(fabsf(q1) + 1e-08f),
-                        gq2 = cE * copysignf(1.f, q2) * t_rcp(fabsf(q2) + 1e-08f);
+            const float gq0 = cE * t_rcp(q0 + 1e-08f), gq1 = cE * t_rcp(q1 + 1e-08f), gq2 = cE * t_rcp(q2 + 1e-08f);
             gt0 += gq0 * (-2.f * t0 * d1_0 * d2_0); gt1 += gq1 * (-2.f * t1 * d1_1 * d2_1); gt2 += gq2 * (-2.f * t2 * d1_2 * d2_2);
             gth.add(36 + f, gq0 * (1.f - t0 * t0) * d2_0); gth.add(40 + f, gq1 * (1.f - t1 * t1) * d2_1); gth.add(44 + f, gq2 * (1.f - t2 * t2) * d2_2);
             gth.add(48 + f, gq0 * (1.f - t0 * t0) * d1_0); gth.add(52 + f, gq1 * (1.f - t1 * t1) * d1_1); gth.add(56 + f, gq2 * (1.f - t2 * t2) * d1_2);
@@ -92,8 +93,8 @@ __device__ __forceinline__ void flows_adjoint(const float (&th)[84], GACC& gth, 
             float gta = ga * d1;
             gth.add(72 + f, ga * tav);
             if (cE != 0.f && valid) {
-                const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;
-                const float gq = cE * copysignf(1.f, q) * t_rcp(fabsf(q) + 1e-08f);
+                const float q = (1.f - tav * tav) * (d1 * d2) + 1.f;          // >= 0, see above
+                const float gq = cE * t_rcp(q + 1e-08f);
                 gta += gq * (-2.f * tav * d1 * d2);
                 gth.add(72 + f, gq * (1.f - tav * tav) * d2);
                 gth.add(76 + f, gq * (1.f - tav * tav) * d1);
