@@ -37,11 +37,32 @@ rows = [("`fused_fwd_kernel<256, 0, true, 0, true>` (train, Q4)", "train", "fuse
         ("`tail_bwd_kernel`", "train", "tail_bwd_kernel", None, "VALU issue"),
         ("`tail_bwd_kernel` at K = 64", "k64_train", "tail_bwd_kernel", None, "VALU issue"),
         ("`fused_fwd_kernel<512, 0, true, 0, true>` (W512)", "w512_train", "fused_fwd_kernel<512, 0, true, 0, true>", 308.57, "(W512: 308.6 GFLOP)")]
+
+
+def pmc_bytes(kernel):
+    """HBM bytes per launch from the round's PMC summary (first FETCH_SIZE / WRITE_SIZE pass that lists the kernel; KB, FETCH x 2 on gfx950)"""
+    import re
+    f = w = None
+    for ln in open(os.path.join(P, f"{tag}_pmc_summary.txt")):
+        if ln.startswith(kernel):
+            m = re.search(r"FETCH_SIZE=([0-9.e+]+)", ln)
+            if m and f is None:
+                f = float(m.group(1))
+            m = re.search(r"WRITE_SIZE=([0-9.e+]+)", ln)
+            if m and w is None:
+                w = float(m.group(1))
+    return (2 * f + w) * 1024
+
+
 kt = "| kernel (C2 unless named) | csv (`profiles/`) | rocprofv3 avg ms | of its bound |\n|---|---|---|---|\n"
 for label, stats, kern, gf, note in rows:
     name = f"{tag}_{stats}_kernel_stats.csv"
     a = avg(name, kern)
     frac = f"{gf / a / PEAK:.3f} {note}".strip() if gf else note
+    if kern == "dw_small_kernel":               # its bound is HBM: quote both
+        b = pmc_bytes("dw_small_kernel")
+        frac = (f"{gf / a / PEAK:.3f} of the MFMA peak (15.5 GFLOP); **HBM-bound**: {b / 1e9:.3f} GB (PMC) ÷ {a:.4f} ms = {b / a / 1e9:.2f} TB/s = "
+                f"{b / a / 1e9 / 8.0:.2f} of the 8 TB/s spec ({b / a / 1e9 / 6.29:.2f} of the 6.29 TB/s measured achievable)")
     kt += f"| {label} | `{name}` | {a:.4f} | {frac} |\n"
 
 bt = ("| config | rays/s | ms / step | fused forward ms (frac of 157.3 TF, HIP events) | backward-data | dW leg | tail | whole step of peak |\n"
